@@ -1,0 +1,93 @@
+"""ctypes binding of libgpbo.so (the C ABI declared in include/gpbo.h).
+
+There is no CPU fallback: if the shared library is missing the import of the
+compute layer fails with an explicit message telling how to build it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgpbo.so')
+
+OK, ERR_NOT_PD, ERR_BAD_ARG, ERR_HIP = 0, 1, 2, 3
+KERNEL_RBF, KERNEL_MATERN52 = 0, 1
+VARIANT_V4, VARIANT_SINGLE = 0, 1
+ACQ_EI, ACQ_UCB, ACQ_PI = 0, 1, 2
+INCUMBENT_MAX_MU, INCUMBENT_MAX_Y, INCUMBENT_GIVEN = 0, 1, 2
+
+
+class Timings(C.Structure):
+    _fields_ = [(k, C.c_double) for k in (
+        'fit_total_ms', 'kbuild_ms', 'chol_ms', 'chol_count', 'trsv_ms', 'inverse_ms',
+        'posterior_total_ms', 'ksbuild_ms', 'trmm_ms', 'trmm_launches', 'finalize_ms',
+        'acquire_ms', 'trmm_flops')] + [('reserved', C.c_double * 3)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
+
+
+class StateDesc(C.Structure):
+    _fields_ = [('n', C.c_int64), ('n_pad', C.c_int64),
+                ('d', C.c_int32), ('kernel', C.c_int32), ('variant', C.c_int32), ('pad_', C.c_int32),
+                ('sigmaY', C.c_double),
+                ('W', C.c_void_p), ('W_bytes', C.c_int64),
+                ('alpha', C.c_void_p), ('alpha_bytes', C.c_int64),
+                ('Xts', C.c_void_p), ('Xts_bytes', C.c_int64),
+                ('params', C.c_void_p), ('params_bytes', C.c_int64),
+                ('y_max', C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); every symbol include/gpbo.h declares
+SIGNATURES = {
+    'gpbo_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    'gpbo_destroy': (None, [C.c_void_p]),
+    'gpbo_last_error': (C.c_char_p, [C.c_void_p]),
+    'gpbo_last_info': (C.c_int64, [C.c_void_p]),
+    'gpbo_stream': (C.c_void_p, [C.c_void_p]),
+    'gpbo_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, C.c_double, C.c_int32, C.c_int32, _dp, _dp]),
+    'gpbo_set_candidates': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    'gpbo_posterior': (C.c_int, [C.c_void_p, _dp]),
+    'gpbo_acquire': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, _i64p, _dp]),
+    'gpbo_read': (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int64, C.c_int64]),
+    'gpbo_predict_ei': (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_double, C.c_int32, C.c_double, _dp, _dp, _dp, _i64p, _dp, _dp]),
+    'gpbo_append': (C.c_int, [C.c_void_p, _dp, C.c_double, _dp]),
+    'gpbo_lml_batch': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, _dp, _dp, _i32p]),
+    'gpbo_get_factor': (C.c_int, [C.c_void_p, _dp, _dp]),
+    'gpbo_last_timings': (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
+    'gpbo_state_describe': (C.c_int, [C.c_void_p, C.POINTER(StateDesc)]),
+    'gpbo_state_alloc': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
+    'gpbo_state_commit': (C.c_int, [C.c_void_p, C.c_double]),
+    'gpbo_set_chunk': (C.c_int, [C.c_void_p, C.c_int64]),
+    'gpbo_selftest_gemm': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgpbo.so once and attach the prototypes.  Raises ImportError when the
+    library has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libgpbo.so not found at %s: the HIP extension is not built and there is no CPU '
+            'fallback. Build it with: python -c "import __graft_entry__ as g; g.build()"' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)

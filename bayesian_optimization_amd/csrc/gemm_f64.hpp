@@ -1,0 +1,138 @@
+// fp64 MFMA tile engine for gfx950 (MI355X): one 256-thread workgroup computes a
+// 128x128 output tile  acc(i,j) = sum_{k in [k_begin,k_end)} A(i,k) * B(k,j)
+// with v_mfma_f64_16x16x4_f64.  Four waves, 2x2, each owning a 64x64 sub-tile as
+// 4x4 MFMA tiles (64 accumulator doubles per lane).
+//
+// Operands are staged global -> registers -> LDS, 16 k-values per step, double
+// buffered with one barrier per step.  Both operands sit in LDS k-major
+// ([k][x], x contiguous, row pitch 144 doubles = 1152 B == 128 mod 256) so the
+// MFMA fragment reads (lane l: k = l>>4, x = l&15) are conflict-free ds_read_b64.
+//
+// Layout flags: KCONTIG=true  -> element (x,k) at base[x*ld + k]  (row-major, k contiguous)
+//               KCONTIG=false -> element (x,k) at base[k*ld + x]  (x contiguous)
+// All tile origins, leading dimensions and k ranges must be multiples of 16 doubles
+// (callers pad every matrix to a multiple of 128).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gpbo {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TM = 128;
+constexpr int TN = 128;
+constexpr int TK = 16;
+constexpr int LDS_LD = 144;
+constexpr int TILE_DOUBLES = TK * LDS_LD;
+constexpr int GEMM_LDS_DOUBLES = 4 * TILE_DOUBLES;   // 2 buffers x 2 operands = 73,728 B
+constexpr int GEMM_THREADS = 256;
+
+struct Stage {
+    f64x2 v[4];
+};
+
+template <bool KCONTIG>
+__device__ __forceinline__ void load_tile(Stage& s, const double* __restrict__ base, long ld, int k0, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int q = tid + 256 * p;
+        if (KCONTIG) {
+            // one wave-load covers 16 rows x 64 contiguous bytes
+            const int l = q & 63, wb = q >> 6;
+            const int x = (l & 15) + 16 * (wb & 7);
+            const int kp = (l >> 4) + 4 * (wb >> 3);
+            s.v[p] = *reinterpret_cast<const f64x2*>(base + (long)x * ld + k0 + 2 * kp);
+        } else {
+            // one wave-load covers 1 KiB contiguous (one k-row of the tile)
+            const int k = q >> 6, c2 = q & 63;
+            s.v[p] = *reinterpret_cast<const f64x2*>(base + (long)(k0 + k) * ld + 2 * c2);
+        }
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile(const Stage& s, double* lds, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int q = tid + 256 * p;
+        if (KCONTIG) {
+            const int l = q & 63, wb = q >> 6;
+            const int x = (l & 15) + 16 * (wb & 7);
+            const int kp = (l >> 4) + 4 * (wb >> 3);
+            lds[(2 * kp) * LDS_LD + x] = s.v[p].x;
+            lds[(2 * kp + 1) * LDS_LD + x] = s.v[p].y;
+        } else {
+            const int k = q >> 6, c2 = q & 63;
+            *reinterpret_cast<f64x2*>(lds + k * LDS_LD + 2 * c2) = s.v[p];
+        }
+    }
+}
+
+// acc must be zero-initialised (or hold the value to accumulate onto) by the caller.
+template <bool A_KCONTIG, bool B_KCONTIG>
+__device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long lda,
+                                              const double* __restrict__ B, long ldb,
+                                              int k_begin, int k_end, f64x4 (&acc)[4][4], double* lds) {
+    if (k_begin >= k_end) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    Stage sa, sb;
+    load_tile<A_KCONTIG>(sa, A, lda, k_begin, tid);
+    load_tile<B_KCONTIG>(sb, B, ldb, k_begin, tid);
+    store_tile<A_KCONTIG>(sa, lds, tid);
+    store_tile<B_KCONTIG>(sb, lds + TILE_DOUBLES, tid);
+    __syncthreads();
+    int buf = 0;
+    const int frag_off = (lane & 15) + (lane >> 4) * LDS_LD;
+    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+        const bool has_next = (k0 + TK) < k_end;
+        if (has_next) {
+            load_tile<A_KCONTIG>(sa, A, lda, k0 + TK, tid);
+            load_tile<B_KCONTIG>(sb, B, ldb, k0 + TK, tid);
+        }
+        const double* a_l = lds + buf * 2 * TILE_DOUBLES + wr * 64 + frag_off;
+        const double* b_l = lds + buf * 2 * TILE_DOUBLES + TILE_DOUBLES + wc * 64 + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = a_l[kk * 4 * LDS_LD + t * 16];
+                bf[t] = b_l[kk * 4 * LDS_LD + t * 16];
+            }
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
+        }
+        if (has_next) {
+            double* nxt = lds + (buf ^ 1) * 2 * TILE_DOUBLES;
+            store_tile<A_KCONTIG>(sa, nxt, tid);
+            store_tile<B_KCONTIG>(sb, nxt + TILE_DOUBLES, tid);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+// Accumulator element acc[ta][tb][r] of this lane is output (row, col) of the tile:
+__device__ __forceinline__ int acc_row(int ta, int r) {
+    const int tid = threadIdx.x;
+    return ((tid >> 7) & 1) * 64 + ta * 16 + ((tid & 63) >> 4) + 4 * r;
+}
+__device__ __forceinline__ int acc_col(int tb) {
+    const int tid = threadIdx.x;
+    return ((tid >> 6) & 1) * 64 + tb * 16 + (tid & 15);
+}
+
+__device__ __forceinline__ void acc_zero(f64x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+}
+
+}  // namespace gpbo

@@ -1,0 +1,781 @@
+// libgpbo host side: context, memory, launch sequences and the extern "C" entry points
+// declared in include/gpbo.h.  Single GPU per context, one HIP stream, no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpbo.h"
+#include "kernels.hpp"
+
+using namespace gpbo;
+
+namespace {
+
+enum TimeCat { T_KBUILD, T_CHOL, T_TRSV, T_INV, T_KS, T_TRMM, T_FIN, T_ACQ, T_TOTAL, T_NCAT };
+
+struct EvRec {
+    int cat;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct gpbo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int64_t info = 0;
+
+    // model
+    bool fitted = false;
+    int64_t n = 0, n_pad = 0, nb = 0, cap_pad = 0;
+    int d = 0, kernel = 0, variant = 0;
+    double sigmaY = 0, eps = 0, theta1 = 0, nll = 0, y_max = 0;
+    std::vector<double> theta;
+    double *bufA = nullptr, *bufB = nullptr, *bufW = nullptr, *Dinv = nullptr;
+    double *Xts = nullptr, *alpha = nullptr, *alpha1 = nullptr, *yv = nullptr, *work = nullptr, *zv = nullptr;
+    double* params = nullptr;
+    int* info_dev = nullptr;
+    bool have_factor = false;   // bufL valid (false on ranks that only received W)
+    double* bufL = nullptr;     // points at bufA or bufB
+
+    // candidates + outputs
+    double* Xs = nullptr;
+    int64_t m = 0, m_cap = 0;
+    double *mu = nullptr, *var = nullptr, *acq = nullptr;
+    bool have_posterior = false;
+
+    // chunk scratch
+    int64_t chunk_req = 0, chunk = 0, scratch_npad = 0;
+    double *Bmat = nullptr, *partial = nullptr, *mupart = nullptr;
+    int kc = 512;
+
+    // reductions
+    double *red_v = nullptr, *red_v2 = nullptr, *inc_dev = nullptr;
+    long *red_i = nullptr, *red_i2 = nullptr;
+
+    // timing
+    std::vector<EvRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    gpbo_timings tm{};
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            return GPBO_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+#define BADARG(msg)              \
+    do {                         \
+        ctx->err = (msg);        \
+        return GPBO_ERR_BAD_ARG; \
+    } while (0)
+
+#define CHK(expr)                      \
+    do {                               \
+        int s_ = (expr);               \
+        if (s_ != GPBO_OK) return s_;  \
+    } while (0)
+
+int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+hipEvent_t ev_get(gpbo_ctx* ctx) {
+    if (ctx->pool_used == ctx->pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        ctx->pool.push_back(e);
+    }
+    return ctx->pool[ctx->pool_used++];
+}
+
+struct Scope {
+    gpbo_ctx* ctx;
+    EvRec r;
+    Scope(gpbo_ctx* c, int cat) : ctx(c) {
+        r.cat = cat;
+        r.a = ev_get(c);
+        r.b = ev_get(c);
+        hipEventRecord(r.a, c->stream);
+    }
+    ~Scope() {
+        hipEventRecord(r.b, ctx->stream);
+        ctx->recs.push_back(r);
+    }
+};
+
+void timing_begin(gpbo_ctx* ctx) {
+    ctx->recs.clear();
+    ctx->pool_used = 0;
+}
+
+// after a stream sync: accumulate per-category milliseconds
+void timing_collect(gpbo_ctx* ctx, double* ms, double* count) {
+    for (int i = 0; i < T_NCAT; ++i) ms[i] = 0, count[i] = 0;
+    for (auto& r : ctx->recs) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms[r.cat] += t;
+            count[r.cat] += 1;
+        }
+    }
+}
+
+template <typename T>
+int dev_alloc(gpbo_ctx* ctx, T** p, size_t count) {
+    if (*p) {
+        hipFree(*p);
+        *p = nullptr;
+    }
+    HIPCHK(hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return GPBO_OK;
+}
+
+void free_model(gpbo_ctx* ctx) {
+    double** ps[] = {&ctx->bufA, &ctx->bufB, &ctx->bufW, &ctx->Dinv, &ctx->Xts, &ctx->alpha, &ctx->alpha1, &ctx->yv, &ctx->work, &ctx->zv};
+    for (auto p : ps) {
+        if (*p) hipFree(*p);
+        *p = nullptr;
+    }
+    ctx->cap_pad = 0;
+    ctx->fitted = false;
+    ctx->have_factor = false;
+}
+
+// (re)allocate model buffers for n_pad; full = also the factor buffers (fit ranks)
+int ensure_model(gpbo_ctx* ctx, int64_t n_pad, int d, bool full) {
+    const bool need = (n_pad != ctx->cap_pad) || (full && !ctx->bufA) || d > MAX_D;
+    if (d > MAX_D) BADARG("d exceeds 32");
+    if (!need) return GPBO_OK;
+    free_model(ctx);
+    const size_t nn = (size_t)n_pad * n_pad;
+    CHK(dev_alloc(ctx, &ctx->bufW, nn));
+    if (full) {
+        CHK(dev_alloc(ctx, &ctx->bufA, nn));
+        CHK(dev_alloc(ctx, &ctx->bufB, nn));
+        CHK(dev_alloc(ctx, &ctx->Dinv, (size_t)n_pad * PB));
+        CHK(dev_alloc(ctx, &ctx->alpha1, n_pad));
+        CHK(dev_alloc(ctx, &ctx->yv, n_pad));
+        CHK(dev_alloc(ctx, &ctx->work, n_pad));
+        CHK(dev_alloc(ctx, &ctx->zv, n_pad));
+    }
+    CHK(dev_alloc(ctx, &ctx->Xts, (size_t)MAX_D * n_pad));
+    CHK(dev_alloc(ctx, &ctx->alpha, n_pad));
+    ctx->cap_pad = n_pad;
+    return GPBO_OK;
+}
+
+int ensure_scratch(gpbo_ctx* ctx) {
+    // chunk: multiple of 256 candidates; default keeps Bmat <= ~1 GiB but at least 4096 columns
+    int64_t chunk = ctx->chunk_req;
+    if (chunk <= 0) {
+        const char* e = getenv("GPBO_CHUNK");
+        if (e) chunk = atoll(e);
+    }
+    if (chunk <= 0) {
+        chunk = (int64_t)(1ull << 30) / (8 * ctx->n_pad);
+        chunk = std::max<int64_t>(chunk, 4096);
+        chunk = std::min<int64_t>(chunk, 32768);
+    }
+    chunk = round_up(chunk, 256);
+    chunk = std::min<int64_t>(chunk, round_up(std::max<int64_t>(ctx->m, 1), 256));
+    if (chunk == ctx->chunk && ctx->scratch_npad == ctx->n_pad && ctx->Bmat) return GPBO_OK;
+    const int nkc = (int)((ctx->n_pad + ctx->kc - 1) / ctx->kc);
+    CHK(dev_alloc(ctx, &ctx->Bmat, (size_t)ctx->n_pad * chunk));
+    CHK(dev_alloc(ctx, &ctx->partial, (size_t)ctx->nb * chunk));
+    CHK(dev_alloc(ctx, &ctx->mupart, (size_t)nkc * chunk));
+    ctx->chunk = chunk;
+    ctx->scratch_npad = ctx->n_pad;
+    return GPBO_OK;
+}
+
+// ---------------------------------------------------------------- launch sequences
+int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr) {
+    Scope s(ctx, T_KBUILD);
+    dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4));
+    hipLaunchKernelGGL(k_kernel_matrix, grid, dim3(256), 0, ctx->stream, ctx->Xts, (int)ctx->n, (int)ctx->n_pad, ctx->d, K,
+                       scale_ptr, ctx->eps, ctx->kernel);
+    HIPCHK(hipGetLastError());
+    return GPBO_OK;
+}
+
+int launch_cholesky(gpbo_ctx* ctx, double* A) {
+    Scope s(ctx, T_CHOL);
+    const long ld = ctx->n_pad;
+    const int nb = (int)ctx->nb;
+    for (int p = 0; p < nb; ++p) {
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, ctx->stream, A, ld, p, ctx->Dinv, ctx->info_dev);
+        const int T = nb - p - 1;
+        if (T > 0) {
+            hipLaunchKernelGGL(k_trsm_panel, dim3(T), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, p, ctx->Dinv);
+            hipLaunchKernelGGL(k_syrk_update, dim3(T, T), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, p);
+        }
+    }
+    dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4));
+    hipLaunchKernelGGL(k_zero_upper, grid, dim3(256), 0, ctx->stream, A, (int)ctx->n_pad);
+    HIPCHK(hipGetLastError());
+    return GPBO_OK;
+}
+
+// alpha1 = L^-T L^-1 y  (uses Dinv of the factor that was computed last)
+int launch_trsv(gpbo_ctx* ctx, const double* L) {
+    Scope s(ctx, T_TRSV);
+    const long ld = ctx->n_pad;
+    const int nb = (int)ctx->nb;
+    HIPCHK(hipMemcpyAsync(ctx->work, ctx->yv, ctx->n_pad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int p = 0; p < nb; ++p)
+        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nb - p), dim3(256), 0, ctx->stream, L, ld, ctx->Dinv, ctx->work, ctx->zv, p);
+    for (int p = nb - 1; p >= 0; --p)
+        hipLaunchKernelGGL(k_trsv_bwd_step, dim3(p + 1), dim3(256), 0, ctx->stream, L, ld, ctx->Dinv, ctx->zv, ctx->alpha1, p);
+    HIPCHK(hipGetLastError());
+    return GPBO_OK;
+}
+
+// W = inv(L): diagonal blocks from Dinv, then log2(nb) doubling levels
+int launch_inverse(gpbo_ctx* ctx, const double* L, double* W, double* T) {
+    Scope s(ctx, T_INV);
+    const long ld = ctx->n_pad;
+    const int nb = (int)ctx->nb;
+    HIPCHK(hipMemsetAsync(W, 0, (size_t)ctx->n_pad * ctx->n_pad * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_inv_copy_diag, dim3(nb), dim3(256), 0, ctx->stream, W, ld, ctx->Dinv);
+    for (int sb = 1; sb < nb; sb *= 2) {
+        const int pairs = (nb + 2 * sb - 1) / (2 * sb);
+        dim3 grid(sb, sb, pairs);
+        hipLaunchKernelGGL(k_inv_step1, grid, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb);
+        hipLaunchKernelGGL(k_inv_step2, grid, dim3(GEMM_THREADS), 0, ctx->stream, W, (const double*)T, ld, sb, nb);
+    }
+    HIPCHK(hipGetLastError());
+    return GPBO_OK;
+}
+
+template <int D>
+void launch_ks_t(gpbo_ctx* ctx, int64_t j0, dim3 grid) {
+    hipLaunchKernelGGL(k_ks_build<D>, grid, dim3(256), 0, ctx->stream, ctx->Xs, (long)ctx->m, (long)j0, ctx->d, ctx->Xts,
+                       (int)ctx->n, (int)ctx->n_pad, ctx->alpha, ctx->params, ctx->Bmat, (long)ctx->chunk, ctx->mupart, ctx->kc,
+                       ctx->kernel);
+}
+
+void launch_ks(gpbo_ctx* ctx, int64_t j0, dim3 grid) {
+    switch (ctx->d) {
+        case 1: launch_ks_t<1>(ctx, j0, grid); break;
+        case 2: launch_ks_t<2>(ctx, j0, grid); break;
+        case 3: launch_ks_t<3>(ctx, j0, grid); break;
+        case 4: launch_ks_t<4>(ctx, j0, grid); break;
+        case 5: launch_ks_t<5>(ctx, j0, grid); break;
+        case 6: launch_ks_t<6>(ctx, j0, grid); break;
+        case 7: launch_ks_t<7>(ctx, j0, grid); break;
+        case 8: launch_ks_t<8>(ctx, j0, grid); break;
+        default: launch_ks_t<0>(ctx, j0, grid); break;
+    }
+}
+
+int reduce_max(gpbo_ctx* ctx, const double* a, int64_t m, double* dst_dev) {
+    const int blocks = (int)std::min<int64_t>(1024, (m + 255) / 256);
+    hipLaunchKernelGGL(k_max_stage, dim3(blocks), dim3(256), 0, ctx->stream, a, (long)m, ctx->red_v);
+    hipLaunchKernelGGL(k_max_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->red_v, (long)blocks, dst_dev);
+    HIPCHK(hipGetLastError());
+    return GPBO_OK;
+}
+
+int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
+    if (!ctx->fitted) BADARG("posterior: no fitted model");
+    if (ctx->m <= 0 || !ctx->Xs) BADARG("posterior: no candidates");
+    CHK(ensure_scratch(ctx));
+    timing_begin(ctx);
+    const int nkc = (int)((ctx->n_pad + ctx->kc - 1) / ctx->kc);
+    const int nb = (int)ctx->nb;
+    double trmm_launches = 0;
+    {
+        Scope tot(ctx, T_TOTAL);
+        for (int64_t j0 = 0; j0 < ctx->m; j0 += ctx->chunk) {
+            const int64_t cols = std::min<int64_t>(ctx->chunk, round_up(ctx->m - j0, 256));   // multiple of 256
+            {
+                Scope s(ctx, T_KS);
+                launch_ks(ctx, j0, dim3((unsigned)(cols / 256), (unsigned)nkc));
+            }
+            {
+                Scope s(ctx, T_TRMM);
+                const int nj = (int)(cols / TN);
+                hipLaunchKernelGGL(k_trmm_sumsq, dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
+                                   (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
+                                   ctx->partial, nb, nj);
+                trmm_launches += 1;
+            }
+            {
+                Scope s(ctx, T_FIN);
+                hipLaunchKernelGGL(k_finalize, dim3((unsigned)(cols / 256)), dim3(256), 0, ctx->stream,
+                                   (const double*)ctx->partial, (const double*)ctx->mupart, (long)ctx->chunk, nb, nkc,
+                                   (const double*)ctx->params, ctx->mu, ctx->var, (long)j0, (long)ctx->m);
+            }
+        }
+        {
+            Scope s(ctx, T_FIN);
+            CHK(reduce_max(ctx, ctx->mu, ctx->m, ctx->inc_dev + 1));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    double mu_max = 0;
+    HIPCHK(hipMemcpyAsync(&mu_max, ctx->inc_dev + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double ms[T_NCAT], cnt[T_NCAT];
+    timing_collect(ctx, ms, cnt);
+    ctx->tm.posterior_total_ms = ms[T_TOTAL];
+    ctx->tm.ksbuild_ms = ms[T_KS];
+    ctx->tm.trmm_ms = ms[T_TRMM];
+    ctx->tm.trmm_launches = trmm_launches;
+    ctx->tm.finalize_ms = ms[T_FIN];
+    ctx->tm.trmm_flops = (double)ctx->n * (double)ctx->n * (double)ctx->m;
+    ctx->have_posterior = true;
+    if (mu_max_out) *mu_max_out = mu_max;
+    return GPBO_OK;
+}
+
+int acquire_impl(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumbent, int64_t* argmax_out, double* best_out) {
+    if (!ctx->have_posterior) BADARG("acquire: no posterior (call gpbo_posterior first)");
+    if (acq < 0 || acq > 2) BADARG("acquire: unknown acquisition");
+    timing_begin(ctx);
+    {
+        Scope s(ctx, T_ACQ);
+        if (mode == GPBO_INCUMBENT_MAX_MU)
+            hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, (const double*)(ctx->inc_dev + 1));
+        else if (mode == GPBO_INCUMBENT_MAX_Y)
+            hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, ctx->y_max);
+        else if (mode == GPBO_INCUMBENT_GIVEN)
+            hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, incumbent);
+        else
+            BADARG("acquire: unknown incumbent mode");
+        hipLaunchKernelGGL(k_acquire, dim3((unsigned)((ctx->m + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->mu,
+                           (const double*)ctx->var, (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq);
+        const int blocks = (int)std::min<int64_t>(1024, (ctx->m + 255) / 256);
+        hipLaunchKernelGGL(k_argmax_stage, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->acq, (const long*)nullptr,
+                           (long)ctx->m, ctx->red_v, ctx->red_i);
+        hipLaunchKernelGGL(k_argmax_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->red_v, (const long*)ctx->red_i,
+                           (long)blocks, ctx->red_v2, ctx->red_i2);
+    }
+    HIPCHK(hipGetLastError());
+    double bv = 0;
+    long bi = 0;
+    HIPCHK(hipMemcpyAsync(&bv, ctx->red_v2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&bi, ctx->red_i2, sizeof(long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double ms[T_NCAT], cnt[T_NCAT];
+    timing_collect(ctx, ms, cnt);
+    ctx->tm.acquire_ms = ms[T_ACQ];
+    if (bi == INT64_MAX) bi = 0;   // all NaN / -inf: numpy.argmax would also give the first element
+    if (argmax_out) *argmax_out = bi;
+    if (best_out) *best_out = bv;
+    return GPBO_OK;
+}
+
+int set_candidates_impl(gpbo_ctx* ctx, const double* Xs, int64_t m, int on_device) {
+    if (!Xs || m <= 0) BADARG("set_candidates: empty candidate set");
+    if (!ctx->fitted) BADARG("set_candidates: fit first (the candidate width is the model's d)");
+    if (m > ctx->m_cap) {
+        CHK(dev_alloc(ctx, &ctx->Xs, (size_t)m * ctx->d));
+        CHK(dev_alloc(ctx, &ctx->mu, m));
+        CHK(dev_alloc(ctx, &ctx->var, m));
+        CHK(dev_alloc(ctx, &ctx->acq, m));
+        ctx->m_cap = m;
+    }
+    ctx->m = m;
+    ctx->have_posterior = false;
+    HIPCHK(hipMemcpyAsync(ctx->Xs, Xs, (size_t)m * ctx->d * sizeof(double),
+                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GPBO_OK;
+}
+
+}  // namespace
+
+// ======================================================================== extern "C"
+extern "C" {
+
+int gpbo_create(int device, gpbo_ctx** out) {
+    if (!out) return GPBO_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return GPBO_ERR_HIP;
+    gpbo_ctx* ctx = new gpbo_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return GPBO_ERR_HIP;
+    }
+    bool ok = hipMalloc((void**)&ctx->params, PARAMS_DOUBLES * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&ctx->info_dev, sizeof(int)) == hipSuccess &&
+              hipMalloc((void**)&ctx->red_v, 1024 * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&ctx->red_i, 1024 * sizeof(long)) == hipSuccess &&
+              hipMalloc((void**)&ctx->red_v2, 8 * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&ctx->red_i2, 8 * sizeof(long)) == hipSuccess &&
+              hipMalloc((void**)&ctx->inc_dev, 8 * sizeof(double)) == hipSuccess;
+    if (!ok) {
+        gpbo_destroy(ctx);
+        return GPBO_ERR_HIP;
+    }
+    hipMemset(ctx->params, 0, PARAMS_DOUBLES * sizeof(double));
+    *out = ctx;
+    return GPBO_OK;
+}
+
+void gpbo_destroy(gpbo_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    free_model(ctx);
+    void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
+                  ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart};
+    for (void* p : ps)
+        if (p) hipFree(p);
+    for (auto e : ctx->pool) hipEventDestroy(e);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* gpbo_last_error(gpbo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int64_t gpbo_last_info(gpbo_ctx* ctx) { return ctx ? ctx->info : 0; }
+void* gpbo_stream(gpbo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int gpbo_set_chunk(gpbo_ctx* ctx, int64_t chunk) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (chunk < 0) BADARG("set_chunk: negative");
+    ctx->chunk_req = chunk;
+    return GPBO_OK;
+}
+
+int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, const double* theta, double sigmaY,
+             int32_t kernel, int32_t variant, double* theta1_out, double* nll_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!X || !y || !theta) BADARG("fit: null input");
+    if (n <= 0 || d <= 0 || d > MAX_D) BADARG("fit: need n >= 1 and 1 <= d <= 32");
+    if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN52) BADARG("fit: unknown kernel");
+    if (variant != GPBO_VARIANT_V4 && variant != GPBO_VARIANT_SINGLE) BADARG("fit: unknown variant");
+    if (!(sigmaY >= 0)) BADARG("fit: sigmaY must be >= 0");
+    for (int t = 0; t < d; ++t)
+        if (!(theta[t] != 0.0) || !std::isfinite(theta[t])) BADARG("fit: theta entries must be finite and non-zero");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n_pad = round_up(n, PB);
+    CHK(ensure_model(ctx, n_pad, d, true));
+    ctx->fitted = false;
+    ctx->have_posterior = false;
+    ctx->n = n;
+    ctx->n_pad = n_pad;
+    ctx->nb = n_pad / PB;
+    ctx->d = d;
+    ctx->kernel = kernel;
+    ctx->variant = variant;
+    ctx->sigmaY = sigmaY;
+    ctx->eps = (sigmaY == 0) ? 1e-15 * (double)n : sigmaY * sigmaY;   // BayesOpt_v4.ipynb:138-141
+    ctx->theta.assign(theta, theta + d);
+    ctx->info = 0;
+
+    // host staging: X/theta dimension-major, padded y, 1/theta
+    std::vector<double> xts((size_t)d * n_pad, 0.0), yp(n_pad, 0.0), par(PARAMS_DOUBLES, 0.0);
+    for (int t = 0; t < d; ++t) {
+        const double it = 1.0 / theta[t];
+        par[P_INVTHETA + t] = it;
+        for (int64_t i = 0; i < n; ++i) xts[(size_t)t * n_pad + i] = X[i * d + t] * it;
+    }
+    for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
+    HIPCHK(hipMemcpyAsync(ctx->Xts, xts.data(), xts.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->yv, yp.data(), yp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->params, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // staging vectors die at scope end
+
+    timing_begin(ctx);
+    double nchol = 0;
+    {
+        Scope tot(ctx, T_TOTAL);
+        CHK(launch_kernel_matrix(ctx, ctx->bufA, nullptr));
+        CHK(launch_cholesky(ctx, ctx->bufA));
+        nchol += 1;
+        CHK(launch_trsv(ctx, ctx->bufA));
+        hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bufA, (long)n_pad,
+                           (const double*)ctx->yv, (const double*)ctx->alpha1, ctx->alpha, (int)n, (int)n_pad, variant, ctx->params);
+        if (variant == GPBO_VARIANT_V4) {
+            CHK(launch_kernel_matrix(ctx, ctx->bufB, ctx->params + P_THETA1));   // theta1*K0 + eps, :146-147
+            CHK(launch_cholesky(ctx, ctx->bufB));
+            nchol += 1;
+            CHK(launch_inverse(ctx, ctx->bufB, ctx->bufW, ctx->bufA));
+            ctx->bufL = ctx->bufB;
+        } else {
+            CHK(launch_inverse(ctx, ctx->bufA, ctx->bufW, ctx->bufB));
+            ctx->bufL = ctx->bufA;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    double par_out[8];
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(par_out, ctx->params, sizeof(par_out), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double ms[T_NCAT], cnt[T_NCAT];
+    timing_collect(ctx, ms, cnt);
+    ctx->tm.fit_total_ms = ms[T_TOTAL];
+    ctx->tm.kbuild_ms = ms[T_KBUILD];
+    ctx->tm.chol_ms = ms[T_CHOL];
+    ctx->tm.chol_count = nchol;
+    ctx->tm.trsv_ms = ms[T_TRSV];
+    ctx->tm.inverse_ms = ms[T_INV];
+    if (info != 0) {
+        ctx->info = info;
+        ctx->err = "fit: matrix is not positive definite (pivot <= 0 at row " + std::to_string(info) + ")";
+        return GPBO_ERR_NOT_PD;
+    }
+    ctx->theta1 = par_out[P_THETA1];
+    ctx->nll = par_out[P_NLL];
+    ctx->y_max = par_out[P_YMAX];
+    if (!(ctx->theta1 > 0) || !std::isfinite(ctx->theta1)) {
+        // the second factor of a non-positive theta1 would have failed above; NaN means garbage in
+        ctx->err = "fit: theta1 = y^T alpha / n is not positive/finite";
+        ctx->info = 0;
+        return GPBO_ERR_NOT_PD;
+    }
+    ctx->fitted = true;
+    ctx->have_factor = true;
+    if (theta1_out) *theta1_out = ctx->theta1;
+    if (nll_out) *nll_out = ctx->nll;
+    return GPBO_OK;
+}
+
+int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xs, int64_t m, int32_t on_device) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    return set_candidates_impl(ctx, Xs, m, on_device);
+}
+
+int gpbo_posterior(gpbo_ctx* ctx, double* mu_max_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    return posterior_impl(ctx, mu_max_out);
+}
+
+int gpbo_acquire(gpbo_ctx* ctx, int32_t acq, double kappa, int32_t incumbent_mode, double incumbent, int64_t* argmax_out,
+                 double* best_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    return acquire_impl(ctx, acq, kappa, incumbent_mode, incumbent, argmax_out, best_out);
+}
+
+int gpbo_read(gpbo_ctx* ctx, double* mu, double* var, double* acq, int64_t offset, int64_t count) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (offset < 0 || count < 0 || offset + count > ctx->m) BADARG("read: range outside the candidate set");
+    if (!ctx->have_posterior) BADARG("read: no posterior");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)count * sizeof(double);
+    if (mu) HIPCHK(hipMemcpyAsync(mu, ctx->mu + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (var) HIPCHK(hipMemcpyAsync(var, ctx->var + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (acq) HIPCHK(hipMemcpyAsync(acq, ctx->acq + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GPBO_OK;
+}
+
+int gpbo_predict_ei(gpbo_ctx* ctx, const double* Xs, int64_t m, double kappa, int32_t incumbent_mode, double incumbent,
+                    double* mu_out, double* var_out, double* ei_out, int64_t* argmax_out, double* ei_max_out,
+                    double* mu_max_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(set_candidates_impl(ctx, Xs, m, 0));
+    CHK(posterior_impl(ctx, mu_max_out));
+    CHK(acquire_impl(ctx, GPBO_ACQ_EI, kappa, incumbent_mode, incumbent, argmax_out, ei_max_out));
+    return gpbo_read(ctx, mu_out, var_out, ei_out, 0, m);
+}
+
+int gpbo_get_factor(gpbo_ctx* ctx, double* L_out, double* alpha_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!ctx->fitted) BADARG("get_factor: no fitted model");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (L_out) {
+        if (!ctx->have_factor) BADARG("get_factor: this context holds a received model without the factor");
+        HIPCHK(hipMemcpy2DAsync(L_out, ctx->n * sizeof(double), ctx->bufL, ctx->n_pad * sizeof(double), ctx->n * sizeof(double),
+                                ctx->n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (alpha_out) HIPCHK(hipMemcpyAsync(alpha_out, ctx->alpha, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GPBO_OK;
+}
+
+int gpbo_last_timings(gpbo_ctx* ctx, gpbo_timings* out) {
+    if (!ctx || !out) return GPBO_ERR_BAD_ARG;
+    *out = ctx->tm;
+    return GPBO_OK;
+}
+
+int gpbo_state_describe(gpbo_ctx* ctx, gpbo_state_desc* out) {
+    if (!ctx || !out) return GPBO_ERR_BAD_ARG;
+    if (!ctx->bufW || ctx->n <= 0) BADARG("state_describe: no model buffers");
+    memset(out, 0, sizeof(*out));
+    out->n = ctx->n;
+    out->n_pad = ctx->n_pad;
+    out->d = ctx->d;
+    out->kernel = ctx->kernel;
+    out->variant = ctx->variant;
+    out->sigmaY = ctx->sigmaY;
+    out->W = ctx->bufW;
+    out->W_bytes = (int64_t)ctx->n_pad * ctx->n_pad * 8;
+    out->alpha = ctx->alpha;
+    out->alpha_bytes = ctx->n_pad * 8;
+    out->Xts = ctx->Xts;
+    out->Xts_bytes = (int64_t)MAX_D * ctx->n_pad * 8;
+    out->params = ctx->params;
+    out->params_bytes = PARAMS_DOUBLES * 8;
+    out->y_max = ctx->y_max;
+    return GPBO_OK;
+}
+
+int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int32_t d, int32_t kernel, int32_t variant, double sigmaY) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (n <= 0 || d <= 0 || d > MAX_D) BADARG("state_alloc: bad shape");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n_pad = round_up(n, PB);
+    if (n_pad != ctx->cap_pad) CHK(ensure_model(ctx, n_pad, d, false));
+    ctx->fitted = false;
+    ctx->have_posterior = false;
+    ctx->have_factor = false;
+    ctx->n = n;
+    ctx->n_pad = n_pad;
+    ctx->nb = n_pad / PB;
+    ctx->d = d;
+    ctx->kernel = kernel;
+    ctx->variant = variant;
+    ctx->sigmaY = sigmaY;
+    ctx->eps = (sigmaY == 0) ? 1e-15 * (double)n : sigmaY * sigmaY;
+    return GPBO_OK;
+}
+
+int gpbo_state_commit(gpbo_ctx* ctx, double y_max) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!ctx->bufW || ctx->n <= 0) BADARG("state_commit: call gpbo_state_alloc first");
+    HIPCHK(hipSetDevice(ctx->device));
+    double par_out[8];
+    HIPCHK(hipMemcpy(par_out, ctx->params, sizeof(par_out), hipMemcpyDeviceToHost));
+    ctx->theta1 = par_out[P_THETA1];
+    ctx->nll = par_out[P_NLL];
+    ctx->y_max = y_max;
+    ctx->fitted = true;
+    return GPBO_OK;
+}
+
+int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    (void)x_new;
+    (void)y_new;
+    (void)mu_max_out;
+    BADARG("append: not available in this build");
+}
+
+int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, const double* thetas,
+                   const double* sigmas, int32_t B, int32_t kernel, double* nll_out, double* grad_out, int32_t* status_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    (void)X; (void)y; (void)n; (void)d; (void)thetas; (void)sigmas; (void)B; (void)kernel; (void)nll_out; (void)grad_out; (void)status_out;
+    BADARG("lml_batch: not available in this build");
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- self test of the tile engine
+namespace {
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_selftest_gemm(const double* A, const double* B, double* C, int n, int reps) {
+    __shared__ double lds[GEMM_LDS_DOUBLES];
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    const int ib = blockIdx.y, jb = blockIdx.x;
+    const double* Ap = AK ? A + (long)ib * 128 * n : A + (long)ib * 128;
+    const double* Bp = BKC ? B + (long)jb * 128 * n : B + (long)jb * 128;
+    (void)reps;
+    gemm_tile_128<AK, BKC>(Ap, n, Bp, n, 0, n, acc, lds);
+    double* Ct = C + (long)ib * 128 * n + (long)jb * 128;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ct[(long)acc_row(ta, r) * n + acc_col(tb)] = acc[ta][tb][r];
+}
+
+void launch_selftest(hipStream_t st, int a_kc, int b_kc, const double* A, const double* B, double* C, int n, int reps) {
+    dim3 grid(n / 128, n / 128), blk(GEMM_THREADS);
+    if (a_kc && b_kc) hipLaunchKernelGGL((k_selftest_gemm<true, true>), grid, blk, 0, st, A, B, C, n, reps);
+    else if (a_kc) hipLaunchKernelGGL((k_selftest_gemm<true, false>), grid, blk, 0, st, A, B, C, n, reps);
+    else if (b_kc) hipLaunchKernelGGL((k_selftest_gemm<false, true>), grid, blk, 0, st, A, B, C, n, reps);
+    else hipLaunchKernelGGL((k_selftest_gemm<false, false>), grid, blk, 0, st, A, B, C, n, reps);
+}
+}  // namespace
+
+extern "C" {
+
+int gpbo_selftest_gemm(gpbo_ctx* ctx, int32_t n, double* err_out, double* rate_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (n <= 0 || n % 128) BADARG("selftest: n must be a positive multiple of 128");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    std::vector<double> A(nn), B(nn), C(nn);
+    uint64_t s = 12345;
+    auto rnd = [&]() {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(int)((s >> 40) % 17) - 8.0;   // small integers: products are exact
+    };
+    for (auto& v : A) v = rnd();
+    for (auto& v : B) v = rnd();
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    HIPCHK(hipMalloc((void**)&dA, nn * 8));
+    HIPCHK(hipMalloc((void**)&dB, nn * 8));
+    HIPCHK(hipMalloc((void**)&dC, nn * 8));
+    HIPCHK(hipMemcpy(dA, A.data(), nn * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB, B.data(), nn * 8, hipMemcpyHostToDevice));
+    double worst = 0;
+    const int nchk = std::min(n, 256);
+    for (int mode = 0; mode < 4; ++mode) {
+        const int a_kc = mode & 1, b_kc = (mode >> 1) & 1;
+        launch_selftest(ctx->stream, a_kc, b_kc, dA, dB, dC, n, 1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(C.data(), dC, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        // element (i,k) of A: a_kc ? A[i*n+k] : A[k*n+i];  (k,j) of B: b_kc ? B[j*n+k] : B[k*n+j]
+        for (int i = 0; i < nchk; ++i)
+            for (int j = 0; j < nchk; ++j) {
+                const int ii = (i * 37) % n, jj = (j * 91 + 5) % n;
+                double ref = 0;
+                for (int k = 0; k < n; ++k)
+                    ref += (a_kc ? A[(size_t)ii * n + k] : A[(size_t)k * n + ii]) * (b_kc ? B[(size_t)jj * n + k] : B[(size_t)k * n + jj]);
+                worst = std::max(worst, std::fabs(ref - C[(size_t)ii * n + jj]));
+            }
+    }
+    if (err_out) *err_out = worst;
+    if (rate_out) {
+        const int reps = 1;
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        launch_selftest(ctx->stream, 1, 0, dA, dB, dC, n, reps);
+        hipEventRecord(a, ctx->stream);
+        launch_selftest(ctx->stream, 1, 0, dA, dB, dC, n, reps);
+        hipEventRecord(b, ctx->stream);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        hipEventDestroy(a);
+        hipEventDestroy(b);
+        *rate_out = 2.0 * (double)n * n * n * reps / (ms * 1e-3) / 1e12;
+    }
+    hipFree(dA);
+    hipFree(dB);
+    hipFree(dC);
+    return GPBO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,524 @@
+// Device kernels of libgpbo (gfx950).  Everything is fp64.  Matrices are row-major,
+// padded to a multiple of 128 rows/columns (pad = identity), so no kernel needs edge
+// handling in the training dimension; candidate chunks are padded to 128 columns and
+// the padded columns are computed but never written to the outputs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f64.hpp"
+
+namespace gpbo {
+
+constexpr int PB = 128;    // Cholesky panel / diagonal block
+constexpr int PLD = 130;   // LDS row pitch of the diagonal block (conflict-free pairs)
+
+// params block on the device (doubles)
+enum { P_THETA1 = 0, P_CB = 1, P_C0 = 2, P_C1 = 3, P_NLL = 4, P_YA = 5, P_SUMLOG = 6, P_YMAX = 7, P_INVTHETA = 8 };
+constexpr int PARAMS_DOUBLES = 8 + 32;
+constexpr int MAX_D = 32;
+
+__device__ __forceinline__ double kern_eval(double D, int kernel) {
+    if (kernel == 0) return exp(-0.5 * D);
+    const double r = sqrt(D);
+    const double s5r = 2.23606797749978969641 * r;
+    return (1.0 + s5r + (5.0 / 3.0) * D) * exp(-s5r);
+}
+
+// ---------------------------------------------------------------------------------------
+// K(X,X): full symmetric n_pad x n_pad matrix, scale*k(D) + eps on the diagonal, identity pad.
+// Xts is [d][n_pad] = X / theta.  scale_ptr == nullptr -> 1.
+__global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ Xts, int n, int n_pad, int d,
+                                                       double* __restrict__ K, const double* __restrict__ scale_ptr,
+                                                       double eps, int kernel) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= n_pad || j >= n_pad) return;
+    const double scale = scale_ptr ? *scale_ptr : 1.0;
+    double v;
+    if (i == j) {
+        v = (i < n) ? scale + eps : 1.0;
+    } else if (i < n && j < n) {
+        double D = 0.0;
+        for (int t = 0; t < d; ++t) {
+            const double df = Xts[(long)t * n_pad + i] - Xts[(long)t * n_pad + j];
+            D += df * df;
+        }
+        v = scale * kern_eval(D, kernel);
+    } else {
+        v = 0.0;
+    }
+    K[(long)i * n_pad + j] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Diagonal block p: in-LDS left-looking Cholesky of the 128x128 block, then its inverse.
+// 256 threads = 128 rows x 2 (the pair splits every dot product by parity of k).
+// Writes L (lower, zeros above) back into A and inv(L) (lower, zeros above) into Dinv.
+// info: first failing 1-based global row (pivot <= 0 or NaN), set once.
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
+                                                    int* __restrict__ info) {
+    __shared__ double S[PB * PLD];
+    __shared__ double dg[PB];
+    const int tid = threadIdx.x;
+    double* blk = A + (long)p * PB * ld + (long)p * PB;
+    for (int idx = tid; idx < PB * PB; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        S[r * PLD + c] = blk[(long)r * ld + c];
+    }
+    __syncthreads();
+    const int i = tid >> 1, h = tid & 1;
+    int fail = -1;
+    const double* ri = S + i * PLD;
+    for (int j = 0; j < PB; ++j) {
+        const double* rj = S + j * PLD;
+        double s = 0.0, s2 = 0.0;
+        for (int k = h; k < j; k += 2) {
+            const double ljk = rj[k];
+            s += ri[k] * ljk;
+            s2 += ljk * ljk;
+        }
+        s += __shfl_xor(s, 1);
+        s2 += __shfl_xor(s2, 1);
+        const double piv = rj[j] - s2;
+        if (!(piv > 0.0) && fail < 0) fail = j;
+        const double dj = sqrt(piv);
+        const double v = (ri[j] - s) / dj;
+        if (h == 0) {
+            if (i > j) S[i * PLD + j] = v;
+            if (i == j) dg[j] = dj;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && fail >= 0) atomicCAS(info, 0, p * PB + fail + 1);
+    if (tid < PB) S[tid * PLD + tid] = 1.0 / dg[tid];
+    __syncthreads();
+    // inverse: pair (c,h) builds column c of inv(L) in the upper triangle, S[c][i] = inv(L)[i][c]
+    {
+        const int c = i;
+        const double* rc = S + c * PLD;
+        for (int r = 1; r < PB; ++r) {
+            double s = 0.0;
+            if (r > c) {
+                const double* rr = S + r * PLD;
+                for (int k = c + h; k < r; k += 2) s += rr[k] * rc[k];
+            }
+            s += __shfl_xor(s, 1);
+            if (r > c && h == 0) S[c * PLD + r] = -s / dg[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    double* dinv = Dinv + (long)p * PB * PB;
+    for (int idx = tid; idx < PB * PB; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        double lv, iv;
+        if (c < r) {
+            lv = S[r * PLD + c];
+            iv = S[c * PLD + r];
+        } else if (c == r) {
+            lv = dg[r];
+            iv = S[r * PLD + r];
+        } else {
+            lv = 0.0;
+            iv = 0.0;
+        }
+        blk[(long)r * ld + c] = lv;
+        dinv[idx] = iv;
+    }
+}
+
+// Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_panel(double* __restrict__ A, long ld, int p,
+                                                             const double* __restrict__ Dinv) {
+    __shared__ double lds[GEMM_LDS_DOUBLES];
+    const int ib = p + 1 + blockIdx.x;
+    double* Ap = A + (long)ib * PB * ld + (long)p * PB;
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    // (k,j) of the B operand = inv(L)[j][k]  -> k contiguous, ld 128
+    gemm_tile_128<true, true>(Ap, ld, Dinv + (long)p * PB * PB, PB, 0, PB, acc, lds);
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ap[(long)acc_row(ta, r) * ld + acc_col(tb)] = acc[ta][tb][r];
+}
+
+// Trailing update: A[ib, jb] -= P[ib] * P[jb]^T for p < jb <= ib, P = solved panel p.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restrict__ A, long ld, int p) {
+    const int ib = p + 1 + blockIdx.y;
+    const int jb = p + 1 + blockIdx.x;
+    if (jb > ib) return;
+    __shared__ double lds[GEMM_LDS_DOUBLES];
+    const double* Pi = A + (long)ib * PB * ld + (long)p * PB;
+    const double* Pj = A + (long)jb * PB * ld + (long)p * PB;
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128<true, true>(Pi, ld, Pj, ld, 0, PB, acc, lds);
+    double* C = A + (long)ib * PB * ld + (long)jb * PB;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* c = C + (long)acc_row(ta, r) * ld + acc_col(tb);
+                *c -= acc[ta][tb][r];
+            }
+}
+
+// Zero the strict upper triangle (the factorisation leaves stale values there).
+__global__ __launch_bounds__(256) void k_zero_upper(double* __restrict__ A, int n_pad) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i < n_pad && j < n_pad && j > i) A[(long)i * n_pad + j] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Triangular inverse W = inv(L) by recursive doubling over 128-blocks.
+// Level with half-size sb (in blocks); pair q joins A = blocks [a0, a0+sb) and
+// B = blocks [b0, b0+rows) below it:  W[B,A] = -inv(L_BB) * L[B,A] * inv(L_AA).
+__global__ __launch_bounds__(256) void k_inv_copy_diag(double* __restrict__ W, long ld, const double* __restrict__ Dinv) {
+    const int p = blockIdx.x;
+    double* blk = W + (long)p * PB * ld + (long)p * PB;
+    const double* src = Dinv + (long)p * PB * PB;
+    for (int idx = threadIdx.x; idx < PB * PB; idx += 256) blk[(long)(idx >> 7) * ld + (idx & 127)] = src[idx];
+}
+
+// step 1: T[B,A] = L[B,A] * W[A,A]      (W[A,A] lower triangular: k >= j)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __restrict__ L, const double* __restrict__ W,
+                                                            double* __restrict__ T, long ld, int sb, int nb) {
+    const int q = blockIdx.z;
+    const int a0 = 2 * q * sb, b0 = a0 + sb;
+    const int rows = min(sb, nb - b0);
+    const int ib = blockIdx.y, jb = blockIdx.x;
+    if (ib >= rows) return;
+    __shared__ double lds[GEMM_LDS_DOUBLES];
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    const double* Ap = L + (long)(b0 + ib) * PB * ld + (long)a0 * PB;
+    const double* Bp = W + (long)a0 * PB * ld + (long)(a0 + jb) * PB;
+    gemm_tile_128<true, false>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, lds);
+    double* C = T + (long)(b0 + ib) * PB * ld + (long)(a0 + jb) * PB;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = acc[ta][tb][r];
+}
+
+// step 2: W[B,A] = - W[B,B] * T[B,A]    (W[B,B] lower triangular: k <= i)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restrict__ W, const double* __restrict__ T, long ld,
+                                                            int sb, int nb) {
+    const int q = blockIdx.z;
+    const int a0 = 2 * q * sb, b0 = a0 + sb;
+    const int rows = min(sb, nb - b0);
+    const int ib = blockIdx.y, jb = blockIdx.x;
+    if (ib >= rows) return;
+    __shared__ double lds[GEMM_LDS_DOUBLES];
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    const double* Ap = W + (long)(b0 + ib) * PB * ld + (long)b0 * PB;
+    const double* Bp = T + (long)b0 * PB * ld + (long)(a0 + jb) * PB;
+    gemm_tile_128<true, false>(Ap, ld, Bp, ld, 0, (ib + 1) * PB, acc, lds);
+    double* C = W + (long)(b0 + ib) * PB * ld + (long)(a0 + jb) * PB;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = -acc[ta][tb][r];
+}
+
+// ---------------------------------------------------------------------------------------
+// Triangular solves for one right-hand side, one launch per 128-block step.
+// Forward step p: z_p = inv(L_pp) w_p ; w_ib -= L[ib,p] z_p for ib > p.   grid = nb - p.
+__global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, long ld,
+                                                       const double* __restrict__ Dinv, double* __restrict__ w,
+                                                       double* __restrict__ z, int p) {
+    __shared__ double yp[PB];
+    __shared__ double zp[PB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < PB) yp[tid] = w[p * PB + tid];
+    __syncthreads();
+    const double* dinv = Dinv + (long)p * PB * PB;
+    for (int r = wv; r < PB; r += 4) {
+        double s = dinv[r * PB + lane] * yp[lane] + dinv[r * PB + 64 + lane] * yp[64 + lane];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) zp[r] = s;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (tid < PB) z[p * PB + tid] = zp[tid];
+        return;
+    }
+    const int ib = p + blockIdx.x;
+    const double* Lp = L + (long)ib * PB * ld + (long)p * PB;
+    for (int r = wv; r < PB; r += 4) {
+        double s = Lp[(long)r * ld + lane] * zp[lane] + Lp[(long)r * ld + 64 + lane] * zp[64 + lane];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) w[ib * PB + r] -= s;
+    }
+}
+
+// Backward step p (L^T x = z): x_p = inv(L_pp)^T z_p ; z_jb -= L[p,jb]^T x_p for jb < p.  grid = p + 1.
+__global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, long ld,
+                                                       const double* __restrict__ Dinv, double* __restrict__ z,
+                                                       double* __restrict__ x, int p) {
+    __shared__ double zp[PB];
+    __shared__ double xp[PB];
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    if (tid < PB) zp[tid] = z[p * PB + tid];
+    __syncthreads();
+    const double* dinv = Dinv + (long)p * PB * PB;
+    const int c = tid & 127, hh = tid >> 7;
+    {
+        double s = 0.0;
+        for (int r = hh * 64; r < hh * 64 + 64; ++r) s += dinv[r * PB + c] * zp[r];
+        red[tid] = s;
+    }
+    __syncthreads();
+    if (tid < PB) xp[tid] = red[tid] + red[tid + 128];
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (tid < PB) x[p * PB + tid] = xp[tid];
+        return;
+    }
+    const int jb = blockIdx.x - 1;
+    const double* Lp = L + (long)p * PB * ld + (long)jb * PB;
+    double s = 0.0;
+    for (int r = hh * 64; r < hh * 64 + 64; ++r) s += Lp[(long)r * ld + c] * xp[r];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < PB) z[jb * PB + tid] -= red[tid] + red[tid + 128];
+}
+
+// theta1 = y.alpha1/n, sum log diag L, -logL, scale factors and the alpha used for the mean.
+// One workgroup (deterministic order).
+__global__ __launch_bounds__(256) void k_fit_scalars(const double* __restrict__ L, long ld, const double* __restrict__ y,
+                                                     const double* __restrict__ alpha1, double* __restrict__ alpha_out,
+                                                     int n, int n_pad, int variant, double* __restrict__ params) {
+    __shared__ double r1[256];
+    __shared__ double r2[256];
+    __shared__ double r3[256];
+    const int tid = threadIdx.x;
+    double ya = 0.0, sl = 0.0, ym = -INFINITY;
+    for (int i = tid; i < n; i += 256) {
+        ya += y[i] * alpha1[i];
+        sl += log(L[(long)i * ld + i]);
+        ym = fmax(ym, y[i]);
+    }
+    r1[tid] = ya;
+    r2[tid] = sl;
+    r3[tid] = ym;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            r1[tid] += r1[tid + o];
+            r2[tid] += r2[tid + o];
+            r3[tid] = fmax(r3[tid], r3[tid + o]);
+        }
+        __syncthreads();
+    }
+    const double theta1 = r1[0] / n;
+    if (tid == 0) {
+        params[P_YA] = r1[0];
+        params[P_SUMLOG] = r2[0];
+        params[P_THETA1] = theta1;
+        params[P_YMAX] = r3[0];
+        params[P_NLL] = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(theta1) + r2[0];
+        if (variant == 0) {
+            params[P_CB] = theta1;
+            params[P_C0] = theta1;
+            params[P_C1] = 1.0;
+        } else {
+            params[P_CB] = 1.0;
+            params[P_C0] = theta1;
+            params[P_C1] = theta1;
+        }
+    }
+    for (int i = tid; i < n_pad; i += 256) alpha_out[i] = (i < n) ? (variant == 0 ? alpha1[i] / theta1 : alpha1[i]) : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K(X*,X) chunk: Bmat[k][j] = cb * k(D(x_k, xs_j)) for k < n (0 for the pad), j over the chunk
+// (j contiguous), plus partial means  mupart[kc][j] = sum_{k in chunk kc} Bmat[k][j] * alpha[k].
+// One thread per candidate; the training point is wave-uniform (scalar loads).
+template <int D>
+__global__ __launch_bounds__(256) void k_ks_build(const double* __restrict__ Xs, long m, long j0, int d_rt,
+                                                  const double* __restrict__ Xts, int n, int n_pad,
+                                                  const double* __restrict__ alpha, const double* __restrict__ params,
+                                                  double* __restrict__ Bmat, long ldb, double* __restrict__ mupart, int kc,
+                                                  int kernel) {
+    const int d = (D > 0) ? D : d_rt;
+    const long jl = (long)blockIdx.x * 256 + threadIdx.x;   // column in the chunk
+    long j = j0 + jl;
+    if (j >= m) j = m - 1;                                   // padded columns: recompute the last candidate
+    const double cb = params[P_CB];
+    double xs[(D > 0) ? D : MAX_D];
+#pragma unroll
+    for (int t = 0; t < ((D > 0) ? D : MAX_D); ++t)
+        if (t < d) xs[t] = Xs[j * d + t] * params[P_INVTHETA + t];
+    const int k_lo = blockIdx.y * kc;
+    const int k_hi = min(k_lo + kc, n_pad);
+    double mu = 0.0;
+    for (int k = k_lo; k < k_hi; ++k) {
+        double v = 0.0;
+        if (k < n) {
+            double Dq = 0.0;
+#pragma unroll
+            for (int t = 0; t < ((D > 0) ? D : MAX_D); ++t)
+                if (t < d) {
+                    const double df = xs[t] - Xts[(long)t * n_pad + k];
+                    Dq += df * df;
+                }
+            v = cb * kern_eval(Dq, kernel);
+            mu += v * alpha[k];
+        }
+        Bmat[(long)k * ldb + jl] = v;
+    }
+    mupart[(long)blockIdx.y * ldb + jl] = mu;
+}
+
+// V = W * Bmat (W lower triangular), fused epilogue: per-column sum of squares of the
+// 128 rows of the tile -> partial[ib][j].  Tiles are issued heaviest (largest ib) first.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __restrict__ W, long ld,
+                                                             const double* __restrict__ Bmat, long ldb,
+                                                             double* __restrict__ partial, int nb, int nj) {
+    __shared__ double lds[GEMM_LDS_DOUBLES];
+    const int bid = blockIdx.x;
+    const int ib = nb - 1 - bid / nj;
+    const int jb = bid % nj;
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128<true, false>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    double cs[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        double s = 0.0;
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += acc[ta][tb][r] * acc[ta][tb][r];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        cs[tb] = s;
+    }
+    double* red = lds;   // the tile engine ended on a barrier: LDS is free
+    if ((lane >> 4) == 0) {
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) red[wr * 128 + wc * 64 + tb * 16 + lane] = cs[tb];
+    }
+    __syncthreads();
+    if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
+}
+
+// var = c0 - c1 * sum_ib partial[ib][j] (clamped: < 1e-60 -> 0), mu = sum_kc mupart[kc][j].
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, const double* __restrict__ mupart,
+                                                  long ldb, int nb, int nkc, const double* __restrict__ params,
+                                                  double* __restrict__ mu, double* __restrict__ var, long j0, long m) {
+    const long jl = (long)blockIdx.x * 256 + threadIdx.x;
+    const long j = j0 + jl;
+    if (jl >= ldb || j >= m) return;
+    double s = 0.0;
+    for (int ib = 0; ib < nb; ++ib) s += partial[(long)ib * ldb + jl];
+    double mm = 0.0;
+    for (int c = 0; c < nkc; ++c) mm += mupart[(long)c * ldb + jl];
+    double v = params[P_C0] - params[P_C1] * s;
+    if (v < 1e-60) v = 0.0;
+    mu[j] = mm;
+    var[j] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Reductions: max and (value, first index) argmax, two stages, deterministic.
+__global__ __launch_bounds__(256) void k_max_stage(const double* __restrict__ a, long m, double* __restrict__ out) {
+    __shared__ double r[256];
+    const int tid = threadIdx.x;
+    double v = -INFINITY;
+    for (long i = (long)blockIdx.x * 256 + tid; i < m; i += (long)gridDim.x * 256) v = fmax(v, a[i]);
+    r[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) r[tid] = fmax(r[tid], r[tid + o]);
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = r[0];
+}
+
+__device__ __forceinline__ bool better(double v, long i, double bv, long bi) {
+    return (v > bv) || (v == bv && i < bi);
+}
+
+__global__ __launch_bounds__(256) void k_argmax_stage(const double* __restrict__ a, const long* __restrict__ idx_in, long m,
+                                                      double* __restrict__ out_v, long* __restrict__ out_i) {
+    __shared__ double rv[256];
+    __shared__ long ri[256];
+    const int tid = threadIdx.x;
+    double bv = -INFINITY;
+    long bi = INT64_MAX;
+    for (long i = (long)blockIdx.x * 256 + tid; i < m; i += (long)gridDim.x * 256) {
+        const double v = a[i];
+        const long gi = idx_in ? idx_in[i] : i;
+        if (better(v, gi, bv, bi)) {
+            bv = v;
+            bi = gi;
+        }
+    }
+    rv[tid] = bv;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o && better(rv[tid + o], ri[tid + o], rv[tid], ri[tid])) {
+            rv[tid] = rv[tid + o];
+            ri[tid] = ri[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out_v[blockIdx.x] = rv[0];
+        out_i[blockIdx.x] = ri[0];
+    }
+}
+
+// Standard normal CDF with the branch structure of Cephes ndtr (what scipy.stats.norm.cdf calls).
+__device__ __forceinline__ double ndtr_dev(double a) {
+    const double x = a * 0.70710678118654752440;
+    const double z = fabs(x);
+    if (z < 0.70710678118654752440) return 0.5 + 0.5 * erf(x);
+    double y = 0.5 * erfc(z);
+    if (x > 0) y = 1.0 - y;
+    return y;
+}
+
+// Acquisition over the resident posterior.  inc_ptr: device scalar incumbent (EI/PI).
+__global__ __launch_bounds__(256) void k_acquire(const double* __restrict__ mu, const double* __restrict__ var, long m, int acq,
+                                                 double kappa, const double* __restrict__ inc_ptr,
+                                                 double* __restrict__ out) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const double sigma = sqrt(var[j]);
+    double r;
+    if (acq == 0) {
+        const double imp = mu[j] - *inc_ptr - kappa;
+        const double Z = imp / sigma;
+        r = imp * ndtr_dev(Z) + sigma * (exp(-Z * Z / 2.0) / 2.50662827463100050242);
+        if (sigma == 0.0) r = 0.0;
+    } else if (acq == 1) {
+        r = mu[j] + kappa * sigma;
+    } else {
+        r = ndtr_dev((mu[j] - *inc_ptr) / sigma);
+    }
+    out[j] = r;
+}
+
+__global__ void k_set_scalar(double* dst, double v) { *dst = v; }
+__global__ void k_copy_scalar(double* dst, const double* src) { *dst = *src; }
+
+}  // namespace gpbo

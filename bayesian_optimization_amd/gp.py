@@ -1,0 +1,188 @@
+"""Host-side object API over the C ABI: one ``GP`` = one GPU context.
+
+fit -> set_candidates -> posterior -> acquire mirrors the body of the reference's BO
+loop (BayesOpt/BayesOpt_v4.ipynb:642-647); the notebook-signature wrappers live in
+``notebook_api.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class GpboError(RuntimeError):
+    pass
+
+
+def _f64(a, ndim=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError('expected a %d-D array, got shape %s' % (ndim, a.shape))
+    return a
+
+
+class GP:
+    def __init__(self, device: int = 0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        st = self._lib.gpbo_create(int(device), C.byref(h))
+        if st != L.OK or not h.value:
+            raise GpboError('gpbo_create(device=%d) failed with status %d (no usable GPU?)' % (device, st))
+        self._h = h
+        self.device = int(device)
+        self.n = self.d = self.m = 0
+        self.theta1 = self.nll = float('nan')
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.gpbo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st == L.OK:
+            return
+        msg = self._lib.gpbo_last_error(self._h)
+        msg = msg.decode() if msg else ''
+        if st == L.ERR_NOT_PD:
+            # what np.linalg.cholesky raises at BayesOpt_v4.ipynb:142
+            raise np.linalg.LinAlgError(msg or 'Matrix is not positive definite')
+        if st == L.ERR_BAD_ARG:
+            raise ValueError(msg)
+        raise GpboError('HIP error: ' + msg)
+
+    @property
+    def stream(self):
+        return self._lib.gpbo_stream(self._h)
+
+    def timings(self):
+        t = L.Timings()
+        self._check(self._lib.gpbo_last_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def set_chunk(self, chunk: int):
+        self._check(self._lib.gpbo_set_chunk(self._h, int(chunk)))
+
+    # ------------------------------------------------------------------ model
+    def fit(self, xTrain, yTrain, theta, sigmaY, kernel=L.KERNEL_RBF, variant=L.VARIANT_V4):
+        X = _f64(xTrain, 2)
+        y = _f64(np.asarray(yTrain).reshape(-1), 1)
+        th = _f64(np.asarray(theta).reshape(-1), 1)
+        if y.shape[0] != X.shape[0]:
+            raise ValueError('xTrain has %d rows, yTrain %d' % (X.shape[0], y.shape[0]))
+        if th.shape[0] != X.shape[1]:
+            raise ValueError('theta has %d entries, xTrain %d columns' % (th.shape[0], X.shape[1]))
+        t1, nll = C.c_double(), C.c_double()
+        self._check(self._lib.gpbo_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th),
+                                       float(sigmaY), int(kernel), int(variant), C.byref(t1), C.byref(nll)))
+        self.n, self.d = X.shape
+        self.theta1, self.nll = t1.value, nll.value
+        self.m = 0
+        return self
+
+    def set_candidates(self, xTest):
+        Xs = _f64(xTest, 2)
+        if Xs.shape[1] != self.d:
+            raise ValueError('xTest has %d columns, the model %d' % (Xs.shape[1], self.d))
+        self._check(self._lib.gpbo_set_candidates(self._h, Xs.ctypes.data_as(C.c_void_p), Xs.shape[0], 0))
+        self.m = Xs.shape[0]
+        return self
+
+    def set_candidates_device(self, dev_ptr: int, m: int):
+        """Candidates already in HBM (e.g. a torch tensor's data_ptr()); copied device-to-device."""
+        self._check(self._lib.gpbo_set_candidates(self._h, C.c_void_p(int(dev_ptr)), int(m), 1))
+        self.m = int(m)
+        return self
+
+    def posterior(self):
+        """Mean/variance for the resident candidates (kept in HBM); returns max(mu)."""
+        mm = C.c_double()
+        self._check(self._lib.gpbo_posterior(self._h, C.byref(mm)))
+        return mm.value
+
+    def acquire(self, acq=L.ACQ_EI, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0):
+        """Returns (argmax index, acquisition value there)."""
+        idx, best = C.c_int64(), C.c_double()
+        self._check(self._lib.gpbo_acquire(self._h, int(acq), float(kappa), int(incumbent_mode), float(incumbent),
+                                           C.byref(idx), C.byref(best)))
+        return int(idx.value), best.value
+
+    def read(self, mu=True, var=True, acq=False, offset=0, count=None):
+        count = self.m - offset if count is None else count
+        out = []
+        bufs = []
+        for want in (mu, var, acq):
+            bufs.append(np.empty(count) if want else None)
+        self._check(self._lib.gpbo_read(self._h, *[L.dptr(b) if b is not None else None for b in bufs], int(offset), int(count)))
+        out = [b for b in bufs if b is not None]
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def predict_ei(self, xTest, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0):
+        """One-call path over host buffers: (mu, var, ei, argmax, ei_max, mu_max)."""
+        Xs = _f64(xTest, 2)
+        if Xs.shape[1] != self.d:
+            raise ValueError('xTest has %d columns, the model %d' % (Xs.shape[1], self.d))
+        m = Xs.shape[0]
+        mu, var, ei = np.empty(m), np.empty(m), np.empty(m)
+        idx, eim, mum = C.c_int64(), C.c_double(), C.c_double()
+        self._check(self._lib.gpbo_predict_ei(self._h, L.dptr(Xs), m, float(kappa), int(incumbent_mode), float(incumbent),
+                                              L.dptr(mu), L.dptr(var), L.dptr(ei), C.byref(idx), C.byref(eim), C.byref(mum)))
+        self.m = m
+        return mu, var, ei, int(idx.value), eim.value, mum.value
+
+    def append(self, x_new, y_new):
+        x = _f64(np.asarray(x_new).reshape(-1), 1)
+        if x.shape[0] != self.d:
+            raise ValueError('x_new has %d entries, the model %d columns' % (x.shape[0], self.d))
+        mm = C.c_double()
+        self._check(self._lib.gpbo_append(self._h, L.dptr(x), float(y_new), C.byref(mm)))
+        self.n += 1
+        return mm.value
+
+    def factor(self, want_L=True, want_alpha=True):
+        Lm = np.empty((self.n, self.n)) if want_L else None
+        al = np.empty(self.n) if want_alpha else None
+        self._check(self._lib.gpbo_get_factor(self._h, L.dptr(Lm) if want_L else None, L.dptr(al) if want_alpha else None))
+        return Lm, al
+
+    def lml_batch(self, xTrain, yTrain, thetas, sigmas, kernel=L.KERNEL_RBF, grad=False):
+        X = _f64(xTrain, 2)
+        y = _f64(np.asarray(yTrain).reshape(-1), 1)
+        th = _f64(thetas, 2)
+        sg = _f64(np.asarray(sigmas).reshape(-1), 1)
+        B = th.shape[0]
+        if th.shape[1] != X.shape[1] or sg.shape[0] != B:
+            raise ValueError('thetas must be (B,d) and sigmas (B,)')
+        nll = np.empty(B)
+        g = np.empty((B, X.shape[1])) if grad else None
+        stat = np.zeros(B, dtype=np.int32)
+        self._check(self._lib.gpbo_lml_batch(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th), L.dptr(sg),
+                                             B, int(kernel), L.dptr(nll), L.dptr(g) if grad else None,
+                                             stat.ctypes.data_as(C.POINTER(C.c_int32))))
+        return (nll, g, stat) if grad else (nll, stat)
+
+    def state_desc(self):
+        sd = L.StateDesc()
+        self._check(self._lib.gpbo_state_describe(self._h, C.byref(sd)))
+        return sd
+
+    def state_alloc(self, n, d, kernel, variant, sigmaY):
+        self._check(self._lib.gpbo_state_alloc(self._h, int(n), int(d), int(kernel), int(variant), float(sigmaY)))
+        self.n, self.d = int(n), int(d)
+
+    def state_commit(self, y_max):
+        self._check(self._lib.gpbo_state_commit(self._h, float(y_max)))
+
+    def selftest_gemm(self, n=256, rate=False):
+        err, r = C.c_double(), C.c_double()
+        self._check(self._lib.gpbo_selftest_gemm(self._h, int(n), C.byref(err), C.byref(r) if rate else None))
+        return (err.value, r.value) if rate else err.value

@@ -1,0 +1,161 @@
+/* libgpbo — C ABI of the MI355X (gfx950) GP posterior + acquisition hot path.
+ *
+ * The reference (kgururangan/Bayesian-Optimization) has no FFI or plugin interface;
+ * the boundary this ABI sits behind is the set of Python function signatures in the
+ * function cell of BayesOpt/BayesOpt_v4.ipynb (gprfcn :127-152, expected_improvement
+ * :188-197, mlefcn :154-165) and, for the trend-GP flavour,
+ * BayesOpt/Gaussian_Process_Regression.ipynb (gpr_poly :197-203, y_kriging_v2 :228-234).
+ * Each entry point below names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - all arrays are C-order float64; pointers are HOST pointers unless the name says
+ *     "device"; the caller owns every buffer it passes and the library keeps no host
+ *     pointer after a call returns;
+ *   - every call returns an int status: GPBO_OK, GPBO_ERR_NOT_PD (Cholesky pivot <= 0,
+ *     what numpy.linalg.cholesky reports as LinAlgError; gpbo_last_info() gives the
+ *     1-based failing row), GPBO_ERR_BAD_ARG, GPBO_ERR_HIP (gpbo_last_error() has text);
+ *   - a context owns one GPU's state (device buffers, one HIP stream).  Calls block
+ *     until the results they return are complete.  One context per process and GPU;
+ *     a context is not re-entrant.
+ */
+#ifndef GPBO_H
+#define GPBO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPBO_OK 0
+#define GPBO_ERR_NOT_PD 1
+#define GPBO_ERR_BAD_ARG 2
+#define GPBO_ERR_HIP 3
+
+#define GPBO_KERNEL_RBF 0      /* exp(-D/2), BayesOpt_v4.ipynb:119-124 */
+#define GPBO_KERNEL_MATERN52 1 /* (1+sqrt5 r+5r^2/3)exp(-sqrt5 r); no reference implementation */
+
+#define GPBO_VARIANT_V4 0      /* two-factor posterior, BayesOpt_v4.ipynb:142-151 */
+#define GPBO_VARIANT_SINGLE 1  /* single factor, theta1-scaled variance, GP/BayesOptFcn_v1.m:73-83 */
+
+#define GPBO_ACQ_EI 0          /* BayesOpt_v4.ipynb:188-197 */
+#define GPBO_ACQ_UCB 1         /* GP/BayesOpt_v1.m:248-251 */
+#define GPBO_ACQ_PI 2          /* Gaussian_Process_Regression.ipynb:265-268 */
+
+#define GPBO_INCUMBENT_MAX_MU 0 /* max posterior mean over the candidates, BayesOpt_v4.ipynb:193 */
+#define GPBO_INCUMBENT_MAX_Y 1  /* max(yTrain), GP/GPFR.m:48 */
+#define GPBO_INCUMBENT_GIVEN 2  /* caller-supplied (multi-GPU: the all-reduced max) */
+
+typedef struct gpbo_ctx gpbo_ctx;
+
+/* Milliseconds measured with HIP events on the context's own stream, for the most
+ * recent call of each kind.  *_launches count kernel launches inside that total. */
+typedef struct gpbo_timings {
+    double fit_total_ms;
+    double kbuild_ms;      /* K(X,X) builds */
+    double chol_ms;        /* all Cholesky factorisations of the fit */
+    double chol_count;
+    double trsv_ms;        /* forward + backward solves for alpha */
+    double inverse_ms;     /* triangular inverse W = L^-1 */
+    double posterior_total_ms;
+    double ksbuild_ms;     /* K(X*,X) tile build + mean partials */
+    double trmm_ms;        /* W * Ks^T with fused column sum of squares */
+    double trmm_launches;
+    double finalize_ms;    /* variance/mean finalisation + max(mu) */
+    double acquire_ms;     /* acquisition + argmax */
+    double trmm_flops;     /* algorithmic flops of the trmm launches: n_pad-free count n^2 per candidate */
+    double reserved[3];
+} gpbo_timings;
+
+/* Device-side description of a fitted model, for broadcasting it to other ranks
+ * (every pointer is a DEVICE pointer owned by the context). */
+typedef struct gpbo_state_desc {
+    int64_t n, n_pad;
+    int32_t d, kernel, variant, pad_;
+    double sigmaY;
+    void* W;       int64_t W_bytes;       /* n_pad x n_pad, inverse Cholesky factor, lower */
+    void* alpha;   int64_t alpha_bytes;   /* n_pad */
+    void* Xts;     int64_t Xts_bytes;     /* d x n_pad, training inputs / theta, dimension-major */
+    void* params;  int64_t params_bytes;  /* theta1, scale factors, 1/theta */
+    double y_max;
+} gpbo_state_desc;
+
+int gpbo_create(int device, gpbo_ctx** out);
+void gpbo_destroy(gpbo_ctx* ctx);
+const char* gpbo_last_error(gpbo_ctx* ctx);
+int64_t gpbo_last_info(gpbo_ctx* ctx);
+/* The HIP stream (hipStream_t) every kernel of this context is launched on. */
+void* gpbo_stream(gpbo_ctx* ctx);
+
+/* Fit: everything of gprfcn that does not depend on xTest — K(X,X) (BayesOpt_v4.ipynb:131,134),
+ * jitter rule (:138-141), Cholesky (:142, and :147 for the v4 variant), alpha (:143),
+ * theta1 (:144), and -logL as mlefcn computes it (:154-165).  X is (n,d), y is (n,),
+ * theta is (d,).  theta1_out / nll_out may be NULL. */
+int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d,
+             const double* theta, double sigmaY, int32_t kernel, int32_t variant,
+             double* theta1_out, double* nll_out);
+
+/* Make a candidate set (m,d) resident in HBM.  on_device != 0: Xs is a device pointer
+ * and is copied device-to-device.  Replaces distmat_v2(xTest,xTrain) inputs (:132). */
+int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xs, int64_t m, int32_t on_device);
+
+/* Pass 1 over the resident candidates: posterior mean and variance
+ * (BayesOpt_v4.ipynb:135,146,149-151; only diag(Cov) is formed) kept in HBM, and the
+ * maximum posterior mean of this context's candidates (:193). */
+int gpbo_posterior(gpbo_ctx* ctx, double* mu_max_out);
+
+/* Pass 2: acquisition over the resident posterior + first-occurrence argmax
+ * (expected_improvement :188-197, np.argmax :647).  incumbent is used when
+ * incumbent_mode == GPBO_INCUMBENT_GIVEN.  argmax_out is the index into this
+ * context's candidate set (lowest index on ties); best_out the acquisition there. */
+int gpbo_acquire(gpbo_ctx* ctx, int32_t acq, double kappa, int32_t incumbent_mode,
+                 double incumbent, int64_t* argmax_out, double* best_out);
+
+/* Copy count results starting at candidate offset to host; any pointer may be NULL. */
+int gpbo_read(gpbo_ctx* ctx, double* mu, double* var, double* acq, int64_t offset, int64_t count);
+
+/* One call = set_candidates + posterior + acquire + read: the whole of
+ * gprfcn(xTest,...) followed by expected_improvement and argmax for host buffers. */
+int gpbo_predict_ei(gpbo_ctx* ctx, const double* Xs, int64_t m, double kappa,
+                    int32_t incumbent_mode, double incumbent,
+                    double* mu_out, double* var_out, double* ei_out,
+                    int64_t* argmax_out, double* ei_max_out, double* mu_max_out);
+
+/* Border-append one training point with theta frozen (single-factor variant only)
+ * and update the resident posterior of the candidate set in place.  The reference
+ * refits from scratch each iteration (BayesOpt_v4.ipynb:642-645); this is the same
+ * posterior for frozen theta (GP/BayesOptFcn_v1.m:73-83). */
+int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out);
+
+/* -logL (mlefcn, BayesOpt_v4.ipynb:154-165) and, when grad_out != NULL, its gradient
+ * w.r.t. theta (jacmlefun, GP/BayesOpt_v3.m:392-417; RBF only) for B settings.
+ * thetas is (B,d), sigmas (B,), nll_out (B,), grad_out (B,d).  status_out (B,) may be
+ * NULL; a non-PD setting yields nll = NaN and status GPBO_ERR_NOT_PD for that entry. */
+int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d,
+                   const double* thetas, const double* sigmas, int32_t B, int32_t kernel,
+                   double* nll_out, double* grad_out, int32_t* status_out);
+
+/* The factor gprfcn returns as L (the second one for the v4 variant, :147) as a dense
+ * (n,n) lower-triangular matrix, and alpha as returned at :148,:152.  Either may be NULL. */
+int gpbo_get_factor(gpbo_ctx* ctx, double* L_out, double* alpha_out);
+
+int gpbo_last_timings(gpbo_ctx* ctx, gpbo_timings* out);
+
+/* Multi-GPU: rank 0 fits, gpbo_state_describe() exposes the device buffers that the
+ * other ranks need; they call gpbo_state_alloc() with the same shape, receive the
+ * bytes into the described buffers (RCCL broadcast), then gpbo_state_commit(). */
+int gpbo_state_describe(gpbo_ctx* ctx, gpbo_state_desc* out);
+int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int32_t d, int32_t kernel, int32_t variant, double sigmaY);
+int gpbo_state_commit(gpbo_ctx* ctx, double y_max);
+
+/* Tuning knob: candidates per posterior chunk (multiple of 128; 0 = default). */
+int gpbo_set_chunk(gpbo_ctx* ctx, int64_t chunk);
+
+/* Self-test of the fp64 MFMA tile engine against a host triple loop (max abs error
+ * returned in err_out) and its sustained rate in TFLOP/s (rate_out may be NULL). */
+int gpbo_selftest_gemm(gpbo_ctx* ctx, int32_t n, double* err_out, double* rate_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPBO_H */
