@@ -1,0 +1,118 @@
+"""CPU: the oracle restatement against the golden vectors produced by running the reference
+(oracle/make_golden.py), plus identities for the parts that have no runnable reference."""
+import numpy as np
+import pytest
+
+from conftest import ILL_CONDITIONED, TOL_MU, TOL_VAR, golden, golden_names, relmax
+from oracle import gp_oracle as o
+
+GPR_CASES = golden_names('g1') + golden_names('g2') + golden_names('g3') + golden_names('g4') + golden_names('g5')
+
+
+@pytest.mark.parametrize('name', GPR_CASES)
+def test_gprfcn_ei_against_reference(name):
+    g = golden(name)
+    assert int(g['raised_linalgerror']) == 0
+    mu, var, st = o.gprfcn_diag(g['xTest'], g['xTrain'], g['yTrain'], g['theta'], float(g['sigmaY']))
+    ei = o.expected_improvement(mu, var, float(g['kappa']))
+    loose = name in ILL_CONDITIONED
+    assert relmax(mu, g['Mu']) <= (1e-6 if loose else TOL_MU)
+    assert relmax(var, g['var']) <= (1e-6 if loose else TOL_VAR)
+    assert relmax(ei, g['ei']) <= (1e-6 if loose else TOL_VAR)
+    assert abs(st['nll'] - float(g['nll'])) <= 1e-10 * abs(float(g['nll']))
+    assert o.argmax_first(ei) == int(g['argmax'])
+    assert np.array_equal(var == 0, g['var'] == 0)          # the < 1e-60 clamp hits the same entries
+    if 'L' in g.files:
+        assert relmax(st['L2'], g['L']) <= 1e-9
+    if name != 'g5_dup_train_s0':                            # alpha of a numerically singular K is not reproducible
+        assert relmax(st['alpha'], g['alpha']) <= (1e-4 if loose else 1e-8)
+
+
+def test_mle_grid_against_reference():
+    g = golden('g6_mle_grid')
+    th0 = g['th0']
+    for key, s in (('nll_sigma0', 0.0), ('nll_sigma005', 0.05)):
+        M = np.array([[o.mlefcn(g['xTrain'], g['yTrain'], np.array([a, b]), s) for b in th0] for a in th0])
+        assert np.max(np.abs(M - g[key]) / np.abs(g[key])) <= 1e-9
+
+
+def test_analytic_gradient_matches_reference_finite_differences():
+    # central differences of the REFERENCE's mlefcn (h = 1e-6).  With sigmaY == 0 and long length
+    # scales K + 1e-15*n*I is numerically singular and the reference's own differences are noise
+    # (they change by orders of magnitude with h), so only the well-conditioned points pin the formula.
+    g = golden('g6_mle_grid')
+    checked = 0
+    for si, s in enumerate(g['fd_sigmas']):
+        for pi, pt in enumerate(g['fd_points']):
+            if float(s) == 0.0 and pi > 0:
+                continue
+            grad = o.mle_grad(g['xTrain'], g['yTrain'], pt, float(s))
+            fd = g['fd_grad'][pi, :, si]
+            assert np.max(np.abs(grad - fd)) <= 1e-6 * np.max(np.abs(fd))
+            checked += 1
+    assert checked == 4
+
+
+@pytest.mark.parametrize('name', golden_names('g7'))
+def test_kriging_against_reference(name):
+    g = golden(name)
+    kst = o.kriging_fit(g['xT'], g['yT'], g['theta'], int(g['deg']))
+    mu, mse = o.kriging_predict(kst, g['xS'])
+    assert relmax(kst['beta'], np.atleast_1d(np.squeeze(g['beta']))) <= 1e-9
+    assert abs(kst['cov'] - float(g['cov'])) <= 1e-9 * abs(float(g['cov']))
+    assert relmax(mu, g['mu']) <= 1e-9
+    assert np.max(np.abs(mse - g['mse'])) <= 1e-9 * max(np.max(np.abs(g['mse'])), kst['cov'] ** 2)
+    if 'pi' in g.files:
+        pi = o.probability_of_improvement(mu, np.max(g['yT']), np.sqrt(np.abs(mse)) + 1e-300)
+        assert np.max(np.abs(pi - g['pi'])) <= 1e-7
+
+
+def test_single_factor_variant_equals_v4_without_noise_rescaling():
+    # with sigmaY == 0 the two posteriors agree to O(jitter) (they differ only in where eps enters)
+    g = golden('g3_d4_n64_s0')
+    mu4, var4, _ = o.gprfcn_diag(g['xTest'], g['xTrain'], g['yTrain'], g['theta'], 0.0, variant=o.VARIANT_V4)
+    mu1, var1, _ = o.gprfcn_diag(g['xTest'], g['xTrain'], g['yTrain'], g['theta'], 0.0, variant=o.VARIANT_SINGLE)
+    assert relmax(mu1, mu4) <= 1e-8 and relmax(var1, var4) <= 1e-6
+
+
+def test_append_equals_refit():
+    rng = np.random.default_rng(0)
+    X = rng.random((30, 3)); y = np.sin(X.sum(1)); Xs = rng.random((200, 3))
+    th = np.array([0.4, 0.5, 0.6])
+    st = o.fit(X[:25], y[:25], th, 1e-2, variant=o.VARIANT_SINGLE)
+    for i in range(25, 30):
+        st = o.append_point(st, X[i], y[i])
+    ref = o.fit(X, y, th, 1e-2, variant=o.VARIANT_SINGLE)
+    mu_a, var_a = o.predict(st, Xs)
+    mu_r, var_r = o.predict(ref, Xs)
+    assert relmax(mu_a, mu_r) <= 1e-10 and relmax(var_a, var_r) <= 1e-9
+    assert abs(st['nll'] - ref['nll']) <= 1e-10 * abs(ref['nll'])
+
+
+def test_matern_shares_everything_but_the_kernel_epilogue():
+    rng = np.random.default_rng(1)
+    X = rng.random((40, 2)); y = np.cos(3 * X[:, 0]) + X[:, 1]; Xs = rng.random((100, 2))
+    th = np.array([0.5, 0.7])
+    D = o.scaled_sqdist(Xs, X, th)
+    K = o.kernel_from_sqdist(D, o.MATERN52)
+    r = np.sqrt(D)
+    assert np.allclose(K, (1 + np.sqrt(5) * r + 5 * r ** 2 / 3) * np.exp(-np.sqrt(5) * r), rtol=1e-15)
+    mu, var, st = o.gprfcn_diag(Xs, X, y, th, 1e-2, kernel=o.MATERN52)
+    # posterior interpolates the data up to the noise level and never exceeds the prior variance
+    mu_t, var_t = o.predict(st, X)
+    assert np.max(np.abs(mu_t - y)) < 0.05 and np.all(var <= st['theta1'] * (1 + 1e-12)) and np.all(var >= 0)
+
+
+def test_ei_rules():
+    mu = np.array([0.1, 0.5, 0.5, -1.0])
+    var = np.array([0.04, 0.0, 0.01, 1e-70])
+    ei = o.expected_improvement(mu, var, 0.01)
+    assert ei[1] == 0.0                      # sigma == 0 -> ei = 0  (BayesOpt_v4.ipynb:196)
+    assert np.all(np.isfinite(ei)) and o.argmax_first(ei) == 2
+    assert o.argmax_first(np.array([1.0, 3.0, 3.0])) == 1   # first occurrence
+
+
+def test_splitmix_shards_are_slices():
+    a = o.splitmix64_uniform(9, 1000)
+    b = np.concatenate([o.splitmix64_uniform(9, 400), o.splitmix64_uniform(9, 600, offset=400)])
+    assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 1 and abs(a.mean() - 0.5) < 0.05
