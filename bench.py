@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Benchmark of the GP posterior + EI + argmax sweep (the hot path) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3] [--m M] [--n N_TRAIN]
+
+A step = one full pass over this rank's resident candidate block: K(X*,X) tiles, posterior mean,
+variance (W * Ks^T with fused column sum of squares on fp64 MFMA), max(Mu) [all-reduce], EI, argmax
+[all-gather].  The model is fitted once (rank 0) and broadcast before the timed region; candidates
+are resident in HBM.  value = candidates processed by all ranks / max-over-ranks time.
+Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk (v_mfma_f64_16x16x4: 2048 flop / 64 clk) x 2.4 GHz
+
+
+def cpu_baseline(cfg, X, y, theta, Xs_sample):
+    """The oracle restatement (NumPy + LAPACK threads) timed on the host cores, on a bounded sample."""
+    from oracle import gp_oracle as o
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    st = o.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
+    t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mu, var = o.predict(st, Xs_sample, block=4096)
+    ei = o.expected_improvement(mu, var, cfg['kappa'])
+    int(np.argmax(ei))
+    t_pred = time.perf_counter() - t0
+    return dict(value=len(Xs_sample) / t_pred, unit='candidates/s', cores=int(cores), kind='port',
+                sample='oracle/gp_oracle.py (NumPy/SciPy, LAPACK threads): predict+EI+argmax over the first %d candidates of '
+                       'the same workload after an untimed-in-value fit of n=%d (fit %.2f s)' % (len(Xs_sample), cfg['n'], t_fit),
+                fit_seconds=t_fit), st, (mu, var)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='cfg2')
+    ap.add_argument('--m', type=int, default=0, help='candidates per GPU (default: the config\'s m)')
+    ap.add_argument('--n', type=int, default=0, help='training points (default: the config\'s n)')
+    ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bayesian_optimization_amd import GP, synth
+    from bayesian_optimization_amd import dist as gdist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+
+    cfg = dict(synth.CONFIGS[a.config])
+    if a.n:
+        cfg['n'] = a.n
+    m_per_gpu = a.m if a.m else cfg['m']
+    if a.config == 'cfg3' and not a.m:
+        m_per_gpu = 1 << 18           # default run of the 32k configuration: a bounded slice per GPU (stated in config)
+    lo, hi = rank * m_per_gpu, (rank + 1) * m_per_gpu       # weak scaling: every rank sweeps m_per_gpu candidates
+
+    gp = GP(local_rank)
+    if a.chunk:
+        gp.set_chunk(a.chunk)
+    X, y, theta = synth.training_set(cfg)
+    fit_tm = None
+    if rank == 0:
+        gp.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
+        fit_tm = gp.timings()
+    gdist.broadcast_model(gp, 0)
+    Xs = synth.candidates(cfg, lo, hi)
+    gp.set_candidates(Xs)
+    sweep = gdist.ShardedSweep(gp, offset=lo)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sweep.step(0, cfg['kappa'])
+    barrier()
+    t0 = time.perf_counter()
+    trmm_ms = trmm_launches = ks_ms = post_ms = acq_ms = 0.0
+    for _ in range(a.steps):
+        gidx, gbest, mu_max = sweep.step(0, cfg['kappa'])
+        tm = gp.timings()                      # HIP-event times on the library's own stream, per step
+        trmm_ms += tm['trmm_ms']
+        trmm_launches += tm['trmm_launches']
+        ks_ms += tm['ksbuild_ms']
+        post_ms += tm['posterior_total_ms']
+        acq_ms += tm['acquire_ms']
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n = cfg['n']
+        total = world * m_per_gpu * a.steps
+        flops_per_launch = float(n) * n * (m_per_gpu * a.steps / max(trmm_launches, 1))   # n^2 per candidate x candidates per launch
+        avg_launch_s = trmm_ms * 1e-3 / max(trmm_launches, 1)
+        achieved = flops_per_launch / avg_launch_s / 1e12
+        out = {
+            'metric': 'gp_posterior_ei_candidates_per_sec', 'value': total / dt, 'unit': 'candidates/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s: n=%d train, d=%d, %s, %d candidates per GPU (x%d GPUs), sigmaY=%g, theta=%g, EI kappa=%g'
+                                   % (a.config, n, cfg['d'], 'RBF' if cfg['kernel'] == 0 else 'Matern-5/2', m_per_gpu, world,
+                                      cfg['sigmaY'], cfg['theta'], cfg['kappa']),
+                       'candidates_per_gpu': m_per_gpu, 'n_train': n, 'd': cfg['d'],
+                       'parallelism': 'candidate blocks per rank; all-reduce(max mu) + all-gather(argmax)'},
+            'roofline': {'bound': 'mfma', 'kernel': 'k_trmm_sumsq', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
+                         'launches': trmm_launches},
+            'phases_ms_per_step': {'posterior_total': post_ms / a.steps, 'ks_build': ks_ms / a.steps,
+                                   'trmm_sumsq': trmm_ms / a.steps, 'acquire': acq_ms / a.steps},
+            'argmax': {'index': int(gidx), 'ei': gbest, 'mu_max': mu_max},
+        }
+        if fit_tm:
+            nchol = max(fit_tm['chol_count'], 1)
+            out['fit'] = {'total_ms': fit_tm['fit_total_ms'], 'cholesky_ms_each': fit_tm['chol_ms'] / nchol,
+                          'cholesky_gflops': (n ** 3 / 3.0) / (fit_tm['chol_ms'] / nchol * 1e-3) / 1e9,
+                          'inverse_ms': fit_tm['inverse_ms'], 'trsv_ms': fit_tm['trsv_ms'], 'kbuild_ms': fit_tm['kbuild_ms']}
+        if world == 1 and not a.no_cpu_baseline:
+            ns = 16384 if n <= 8192 else 2048
+            base, st, (mu_o, var_o) = cpu_baseline(cfg, X, y, theta, Xs[:ns])
+            out['cpu_baseline'] = base
+            mu, var = gp.read(offset=0, count=ns)
+            rel = lambda p, q: float(np.max(np.abs(p - q)) / np.max(np.abs(q)))
+            out['parity_vs_oracle'] = {'sample': ns, 'mean_relmax': rel(mu, mu_o), 'var_relmax': rel(var, var_o)}
+        print(json.dumps(out), flush=True)
+    gp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

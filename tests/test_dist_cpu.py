@@ -1,0 +1,70 @@
+"""CPU, world_size 2, gloo: the two exchange steps of the sharded sweep (all-reduce of max(Mu),
+all-gather + first-index argmax) and the block partition, with stand-in local results."""
+import os
+import socket
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bayesian_optimization_amd import dist as gdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        m_total = 1001
+        lo, hi = gdist.shard_range(m_total, rank, world)
+        # a global "EI" array with an exact tie between the two blocks: the lower global index must win
+        ei = np.sin(np.arange(m_total) * 0.37)
+        ei[[100, 900]] = 5.0
+        mu = np.cos(np.arange(m_total) * 0.11)
+        mu_max = gdist.allreduce_max(float(mu[lo:hi].max()))
+        li = int(np.argmax(ei[lo:hi]))
+        best, gi = gdist.global_argmax(float(ei[lo:hi][li]), li, lo)
+        q.put((rank, lo, hi, mu_max, best, gi))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m_total = 1001
+    mu = np.cos(np.arange(m_total) * 0.11)
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == m_total      # contiguous cover
+    for r in res:
+        assert r[3] == mu.max() and r[4] == 5.0 and r[5] == 100                     # same answer on every rank
+
+
+def test_shard_range_covers_everything_once():
+    for m in (1, 7, 64, 1000003):
+        for w in (1, 2, 3, 8):
+            edges = [gdist.shard_range(m, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == m
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pick_best_is_first_occurrence_and_ignores_nan():
+    assert gdist.pick_best([1.0, 3.0, 3.0, float('nan')], [40, 30, 20, 10]) == (3.0, 20)
+    v, i = gdist.pick_best([float('nan')], [5])
+    assert np.isnan(v) and i == 5

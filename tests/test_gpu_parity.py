@@ -186,3 +186,32 @@ def test_full_size_config2_properties(gp0):
     gp0.posterior()
     mu4, var4 = gp0.read()
     assert np.array_equal(mu4, mu[:1 << 16][perm]) and np.array_equal(var4, var[:1 << 16][perm])
+
+
+def test_model_handoff_to_a_second_context_is_bit_exact(gp0):
+    """What a non-fitting rank does: allocate the state, receive the four device buffers (here: a
+    device-to-device copy through the same zero-copy torch views the RCCL broadcast uses), commit."""
+    import torch
+    from bayesian_optimization_amd import GP
+    from bayesian_optimization_amd import dist as gdist
+    X, y, Xs = synth(700, 5, 3000, 55)
+    theta = np.full(5, 0.7)
+    gp0.fit(X, y, theta, 0.1, kernel=bo.KERNEL_MATERN52)
+    src, sd = gdist.model_tensors(gp0)
+    Lm, _ = gp0.factor()
+    W = src[0].reshape(sd.n_pad, sd.n_pad)[:700, :700].cpu().numpy()
+    assert np.max(np.abs(W @ Lm - np.eye(700))) < 1e-9 and np.all(np.triu(W, 1) == 0)   # the view really is inv(L)
+    gp1 = GP(0)
+    gp1.state_alloc(sd.n, sd.d, sd.kernel, sd.variant, sd.sigmaY)
+    dst, _ = gdist.model_tensors(gp1)
+    for a, b in zip(dst, src):
+        a.copy_(b)
+    torch.cuda.synchronize()
+    gp1.state_commit(sd.y_max)
+    r0 = gp0.predict_ei(Xs, 0.01)
+    r1 = gp1.predict_ei(Xs, 0.01)
+    for u, v in zip(r0, r1):
+        assert np.array_equal(u, v)
+    with pytest.raises(ValueError):
+        gp1.factor()                      # a received model carries no Cholesky factor
+    gp1.close()
