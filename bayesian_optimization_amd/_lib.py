@@ -22,7 +22,7 @@ class Timings(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
         'fit_total_ms', 'kbuild_ms', 'chol_ms', 'chol_count', 'trsv_ms', 'inverse_ms',
         'posterior_total_ms', 'ksbuild_ms', 'trmm_ms', 'trmm_launches', 'finalize_ms',
-        'acquire_ms', 'trmm_flops')] + [('reserved', C.c_double * 3)]
+        'acquire_ms', 'trmm_flops', 'append_total_ms', 'append_sweep_ms')] + [('reserved', C.c_double * 1)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
@@ -57,8 +57,10 @@ SIGNATURES = {
     'gpbo_read': (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int64, C.c_int64]),
     'gpbo_predict_ei': (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_double, C.c_int32, C.c_double, _dp, _dp, _dp, _i64p, _dp, _dp]),
     'gpbo_append': (C.c_int, [C.c_void_p, _dp, C.c_double, _dp]),
+    'gpbo_reserve_appends': (C.c_int, [C.c_void_p, C.c_int64]),
     'gpbo_lml_batch': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, _dp, _dp, _i32p]),
     'gpbo_get_factor': (C.c_int, [C.c_void_p, _dp, _dp]),
+    'gpbo_model_scalars': (C.c_int, [C.c_void_p, _dp, _dp, _dp, _i64p]),
     'gpbo_last_timings': (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     'gpbo_state_describe': (C.c_int, [C.c_void_p, C.POINTER(StateDesc)]),
     'gpbo_state_alloc': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),

@@ -18,7 +18,7 @@ using namespace gpbo;
 
 namespace {
 
-enum TimeCat { T_KBUILD, T_CHOL, T_TRSV, T_INV, T_KS, T_TRMM, T_FIN, T_ACQ, T_TOTAL, T_NCAT };
+enum TimeCat { T_KBUILD, T_CHOL, T_TRSV, T_INV, T_KS, T_TRMM, T_FIN, T_ACQ, T_TOTAL, T_SWEEP, T_NCAT };
 
 struct EvRec {
     int cat;
@@ -45,6 +45,15 @@ struct gpbo_ctx {
     int* info_dev = nullptr;
     bool have_factor = false;   // bufL valid (false on ranks that only received W)
     double* bufL = nullptr;     // points at bufA or bufB
+
+    // incremental append (single-factor variant)
+    int64_t reserve = 0;        // rows reserved for appended points (requested before fit)
+    int64_t reserve_left = 0;   // rows still free in the fitted model
+    double *zfw = nullptr, *kvec = nullptr, *lvec = nullptr, *scal = nullptr, *xnew_dev = nullptr;
+    double *Vres = nullptr, *sres = nullptr;
+    int64_t v_cap_rows = 0, v_cap_m = 0;
+    bool inc_valid = false;     // Vres/sres describe the current model and candidates
+    std::vector<double> h_xnew;
 
     // candidates + outputs
     double* Xs = nullptr;
@@ -145,7 +154,8 @@ int dev_alloc(gpbo_ctx* ctx, T** p, size_t count) {
 }
 
 void free_model(gpbo_ctx* ctx) {
-    double** ps[] = {&ctx->bufA, &ctx->bufB, &ctx->bufW, &ctx->Dinv, &ctx->Xts, &ctx->alpha, &ctx->alpha1, &ctx->yv, &ctx->work, &ctx->zv};
+    double** ps[] = {&ctx->bufA, &ctx->bufB, &ctx->bufW, &ctx->Dinv, &ctx->Xts, &ctx->alpha, &ctx->alpha1, &ctx->yv, &ctx->work, &ctx->zv,
+                     &ctx->zfw, &ctx->kvec, &ctx->lvec};
     for (auto p : ps) {
         if (*p) hipFree(*p);
         *p = nullptr;
@@ -171,6 +181,9 @@ int ensure_model(gpbo_ctx* ctx, int64_t n_pad, int d, bool full) {
         CHK(dev_alloc(ctx, &ctx->yv, n_pad));
         CHK(dev_alloc(ctx, &ctx->work, n_pad));
         CHK(dev_alloc(ctx, &ctx->zv, n_pad));
+        CHK(dev_alloc(ctx, &ctx->zfw, n_pad));
+        CHK(dev_alloc(ctx, &ctx->kvec, n_pad));
+        CHK(dev_alloc(ctx, &ctx->lvec, n_pad));
     }
     CHK(dev_alloc(ctx, &ctx->Xts, (size_t)MAX_D * n_pad));
     CHK(dev_alloc(ctx, &ctx->alpha, n_pad));
@@ -203,21 +216,21 @@ int ensure_scratch(gpbo_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------- launch sequences
-int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr) {
+int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, double eps) {
     Scope s(ctx, T_KBUILD);
     dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4));
     hipLaunchKernelGGL(k_kernel_matrix, grid, dim3(256), 0, ctx->stream, ctx->Xts, (int)ctx->n, (int)ctx->n_pad, ctx->d, K,
-                       scale_ptr, ctx->eps, ctx->kernel);
+                       scale_ptr, eps, ctx->kernel);
     HIPCHK(hipGetLastError());
     return GPBO_OK;
 }
 
-int launch_cholesky(gpbo_ctx* ctx, double* A) {
+int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     Scope s(ctx, T_CHOL);
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
     for (int p = 0; p < nb; ++p) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, ctx->stream, A, ld, p, ctx->Dinv, ctx->info_dev);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, ctx->stream, A, ld, p, ctx->Dinv, info_dev);
         const int T = nb - p - 1;
         if (T > 0) {
             hipLaunchKernelGGL(k_trsm_panel, dim3(T), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, p, ctx->Dinv);
@@ -238,6 +251,7 @@ int launch_trsv(gpbo_ctx* ctx, const double* L) {
     HIPCHK(hipMemcpyAsync(ctx->work, ctx->yv, ctx->n_pad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     for (int p = 0; p < nb; ++p)
         hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nb - p), dim3(256), 0, ctx->stream, L, ld, ctx->Dinv, ctx->work, ctx->zv, p);
+    HIPCHK(hipMemcpyAsync(ctx->zfw, ctx->zv, ctx->n_pad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // z = L^-1 y
     for (int p = nb - 1; p >= 0; --p)
         hipLaunchKernelGGL(k_trsv_bwd_step, dim3(p + 1), dim3(256), 0, ctx->stream, L, ld, ctx->Dinv, ctx->zv, ctx->alpha1, p);
     HIPCHK(hipGetLastError());
@@ -294,6 +308,17 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     if (!ctx->fitted) BADARG("posterior: no fitted model");
     if (ctx->m <= 0 || !ctx->Xs) BADARG("posterior: no candidates");
     CHK(ensure_scratch(ctx));
+    const bool keep_v = (ctx->variant == GPBO_VARIANT_SINGLE && ctx->reserve > 0 && ctx->have_factor);   // also after the last append
+    if (keep_v) {
+        const int64_t rows = ctx->n + ctx->reserve_left;
+        if (rows > ctx->v_cap_rows || ctx->m > ctx->v_cap_m || !ctx->Vres) {
+            CHK(dev_alloc(ctx, &ctx->Vres, (size_t)rows * ctx->m));
+            CHK(dev_alloc(ctx, &ctx->sres, (size_t)ctx->m));
+            ctx->v_cap_rows = rows;
+            ctx->v_cap_m = ctx->m;
+        }
+    }
+    ctx->inc_valid = false;
     timing_begin(ctx);
     const int nkc = (int)((ctx->n_pad + ctx->kc - 1) / ctx->kc);
     const int nb = (int)ctx->nb;
@@ -309,16 +334,22 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
             {
                 Scope s(ctx, T_TRMM);
                 const int nj = (int)(cols / TN);
-                hipLaunchKernelGGL(k_trmm_sumsq, dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
-                                   (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
-                                   ctx->partial, nb, nj);
+                if (keep_v)
+                    hipLaunchKernelGGL(k_trmm_sumsq<true>, dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
+                                       (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
+                                       ctx->partial, nb, nj, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n);
+                else
+                    hipLaunchKernelGGL(k_trmm_sumsq<false>, dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
+                                       (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
+                                       ctx->partial, nb, nj, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0);
                 trmm_launches += 1;
             }
             {
                 Scope s(ctx, T_FIN);
                 hipLaunchKernelGGL(k_finalize, dim3((unsigned)(cols / 256)), dim3(256), 0, ctx->stream,
                                    (const double*)ctx->partial, (const double*)ctx->mupart, (long)ctx->chunk, nb, nkc,
-                                   (const double*)ctx->params, ctx->mu, ctx->var, (long)j0, (long)ctx->m);
+                                   (const double*)ctx->params, ctx->mu, ctx->var, (long)j0, (long)ctx->m,
+                                   keep_v ? ctx->sres : (double*)nullptr);
             }
         }
         {
@@ -339,6 +370,82 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     ctx->tm.finalize_ms = ms[T_FIN];
     ctx->tm.trmm_flops = (double)ctx->n * (double)ctx->n * (double)ctx->m;
     ctx->have_posterior = true;
+    ctx->inc_valid = keep_v;
+    if (mu_max_out) *mu_max_out = mu_max;
+    return GPBO_OK;
+}
+
+template <int D>
+void launch_sweep_t(gpbo_ctx* ctx) {
+    hipLaunchKernelGGL(k_append_sweep<D>, dim3((unsigned)((ctx->m + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->Xs,
+                       (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params, (const double*)ctx->lvec,
+                       (const double*)ctx->scal, ctx->Vres, (long)ctx->m, (int)ctx->n, ctx->sres, ctx->mu, ctx->var, ctx->kernel);
+}
+
+int append_impl(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out) {
+    if (!ctx->fitted || !ctx->have_factor) BADARG("append: no fitted model with a factor on this context");
+    if (ctx->variant != GPBO_VARIANT_SINGLE) BADARG("append: only the single-factor variant can be updated incrementally");
+    if (!x_new) BADARG("append: null x_new");
+    if (!ctx->inc_valid) BADARG("append: call gpbo_reserve_appends, gpbo_fit, gpbo_set_candidates and gpbo_posterior first");
+    if (ctx->reserve_left <= 0 || ctx->n + 1 > ctx->n_pad || ctx->n + 1 > ctx->v_cap_rows) BADARG("append: reserved rows exhausted (gpbo_reserve_appends)");
+    const int n = (int)ctx->n;
+    const long ld = ctx->n_pad;
+    ctx->h_xnew.assign(MAX_D, 0.0);
+    for (int t = 0; t < ctx->d; ++t) ctx->h_xnew[t] = x_new[t] / ctx->theta[t];
+    HIPCHK(hipMemcpyAsync(ctx->xnew_dev, ctx->h_xnew.data(), MAX_D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+    timing_begin(ctx);
+    {
+        Scope tot(ctx, T_TOTAL);
+        hipLaunchKernelGGL(k_append_kvec, dim3((unsigned)((ctx->n_pad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xts, n,
+                           (int)ctx->n_pad, ctx->d, (const double*)ctx->xnew_dev, ctx->kvec, ctx->kernel);
+        hipLaunchKernelGGL(k_append_lvec, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const double*)ctx->bufW, ld, n,
+                           (const double*)ctx->kvec, ctx->lvec);
+        hipLaunchKernelGGL(k_append_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->lvec, ctx->zfw, ctx->yv, n,
+                           y_new, ctx->eps, ctx->scal, ctx->params, ctx->bufL, ctx->bufW, ld, ctx->info_dev);
+        hipLaunchKernelGGL(k_append_wrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufW, ld, n,
+                           (const double*)ctx->lvec, (const double*)ctx->scal);
+        hipLaunchKernelGGL(k_append_alpha, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double*)ctx->bufW, ld, n + 1, (const double*)ctx->zfw, ctx->alpha1, ctx->alpha);
+        {
+            Scope sw(ctx, T_SWEEP);
+            switch (ctx->d) {
+                case 1: launch_sweep_t<1>(ctx); break;
+                case 2: launch_sweep_t<2>(ctx); break;
+                case 3: launch_sweep_t<3>(ctx); break;
+                case 4: launch_sweep_t<4>(ctx); break;
+                case 5: launch_sweep_t<5>(ctx); break;
+                case 6: launch_sweep_t<6>(ctx); break;
+                case 7: launch_sweep_t<7>(ctx); break;
+                case 8: launch_sweep_t<8>(ctx); break;
+                default: launch_sweep_t<0>(ctx); break;
+            }
+        }
+        CHK(reduce_max(ctx, ctx->mu, ctx->m, ctx->inc_dev + 1));
+    }
+    HIPCHK(hipGetLastError());
+    double par_out[8], mu_max = 0;
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(par_out, ctx->params, sizeof(par_out), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&mu_max, ctx->inc_dev + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double ms[T_NCAT], cnt[T_NCAT];
+    timing_collect(ctx, ms, cnt);
+    ctx->tm.append_total_ms = ms[T_TOTAL];
+    ctx->tm.append_sweep_ms = ms[T_SWEEP];
+    if (info != 0) {
+        ctx->info = info;
+        ctx->fitted = false;     // the factor row that was written is not usable
+        ctx->inc_valid = false;
+        ctx->err = "append: enlarged matrix is not positive definite";
+        return GPBO_ERR_NOT_PD;
+    }
+    ctx->n += 1;
+    ctx->reserve_left -= 1;
+    ctx->theta1 = par_out[P_THETA1];
+    ctx->nll = par_out[P_NLL];
+    ctx->y_max = par_out[P_YMAX];
     if (mu_max_out) *mu_max_out = mu_max;
     return GPBO_OK;
 }
@@ -392,6 +499,7 @@ int set_candidates_impl(gpbo_ctx* ctx, const double* Xs, int64_t m, int on_devic
     }
     ctx->m = m;
     ctx->have_posterior = false;
+    ctx->inc_valid = false;
     HIPCHK(hipMemcpyAsync(ctx->Xs, Xs, (size_t)m * ctx->d * sizeof(double),
                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -420,7 +528,9 @@ int gpbo_create(int device, gpbo_ctx** out) {
               hipMalloc((void**)&ctx->red_i, 1024 * sizeof(long)) == hipSuccess &&
               hipMalloc((void**)&ctx->red_v2, 8 * sizeof(double)) == hipSuccess &&
               hipMalloc((void**)&ctx->red_i2, 8 * sizeof(long)) == hipSuccess &&
-              hipMalloc((void**)&ctx->inc_dev, 8 * sizeof(double)) == hipSuccess;
+              hipMalloc((void**)&ctx->inc_dev, 8 * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&ctx->scal, 8 * sizeof(double)) == hipSuccess &&
+              hipMalloc((void**)&ctx->xnew_dev, MAX_D * sizeof(double)) == hipSuccess;
     if (!ok) {
         gpbo_destroy(ctx);
         return GPBO_ERR_HIP;
@@ -436,7 +546,8 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_model(ctx);
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
-                  ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart};
+                  ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
+                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres};
     for (void* p : ps)
         if (p) hipFree(p);
     for (auto e : ctx->pool) hipEventDestroy(e);
@@ -466,10 +577,11 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     for (int t = 0; t < d; ++t)
         if (!(theta[t] != 0.0) || !std::isfinite(theta[t])) BADARG("fit: theta entries must be finite and non-zero");
     HIPCHK(hipSetDevice(ctx->device));
-    const int64_t n_pad = round_up(n, PB);
+    const int64_t n_pad = round_up(n + (variant == GPBO_VARIANT_SINGLE ? ctx->reserve : 0), PB);
     CHK(ensure_model(ctx, n_pad, d, true));
     ctx->fitted = false;
     ctx->have_posterior = false;
+    ctx->inc_valid = false;
     ctx->n = n;
     ctx->n_pad = n_pad;
     ctx->nb = n_pad / PB;
@@ -499,15 +611,15 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     double nchol = 0;
     {
         Scope tot(ctx, T_TOTAL);
-        CHK(launch_kernel_matrix(ctx, ctx->bufA, nullptr));
-        CHK(launch_cholesky(ctx, ctx->bufA));
+        CHK(launch_kernel_matrix(ctx, ctx->bufA, nullptr, ctx->eps));
+        CHK(launch_cholesky(ctx, ctx->bufA, ctx->info_dev));
         nchol += 1;
         CHK(launch_trsv(ctx, ctx->bufA));
         hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bufA, (long)n_pad,
                            (const double*)ctx->yv, (const double*)ctx->alpha1, ctx->alpha, (int)n, (int)n_pad, variant, ctx->params);
         if (variant == GPBO_VARIANT_V4) {
-            CHK(launch_kernel_matrix(ctx, ctx->bufB, ctx->params + P_THETA1));   // theta1*K0 + eps, :146-147
-            CHK(launch_cholesky(ctx, ctx->bufB));
+            CHK(launch_kernel_matrix(ctx, ctx->bufB, ctx->params + P_THETA1, ctx->eps));   // theta1*K0 + eps, :146-147
+            CHK(launch_cholesky(ctx, ctx->bufB, ctx->info_dev));
             nchol += 1;
             CHK(launch_inverse(ctx, ctx->bufB, ctx->bufW, ctx->bufA));
             ctx->bufL = ctx->bufB;
@@ -546,6 +658,7 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     }
     ctx->fitted = true;
     ctx->have_factor = true;
+    ctx->reserve_left = (variant == GPBO_VARIANT_SINGLE) ? ctx->reserve : 0;
     if (theta1_out) *theta1_out = ctx->theta1;
     if (nll_out) *nll_out = ctx->nll;
     return GPBO_OK;
@@ -605,6 +718,16 @@ int gpbo_get_factor(gpbo_ctx* ctx, double* L_out, double* alpha_out) {
     }
     if (alpha_out) HIPCHK(hipMemcpyAsync(alpha_out, ctx->alpha, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GPBO_OK;
+}
+
+int gpbo_model_scalars(gpbo_ctx* ctx, double* theta1_out, double* nll_out, double* y_max_out, int64_t* n_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!ctx->fitted) BADARG("model_scalars: no fitted model");
+    if (theta1_out) *theta1_out = ctx->theta1;
+    if (nll_out) *nll_out = ctx->nll;
+    if (y_max_out) *y_max_out = ctx->y_max;
+    if (n_out) *n_out = ctx->n;
     return GPBO_OK;
 }
 
@@ -671,17 +794,130 @@ int gpbo_state_commit(gpbo_ctx* ctx, double y_max) {
 
 int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out) {
     if (!ctx) return GPBO_ERR_BAD_ARG;
-    (void)x_new;
-    (void)y_new;
-    (void)mu_max_out;
-    BADARG("append: not available in this build");
+    HIPCHK(hipSetDevice(ctx->device));
+    return append_impl(ctx, x_new, y_new, mu_max_out);
+}
+
+int gpbo_reserve_appends(gpbo_ctx* ctx, int64_t max_appends) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (max_appends < 0) BADARG("reserve_appends: negative");
+    ctx->reserve = max_appends;
+    return GPBO_OK;
 }
 
 int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, const double* thetas,
                    const double* sigmas, int32_t B, int32_t kernel, double* nll_out, double* grad_out, int32_t* status_out) {
     if (!ctx) return GPBO_ERR_BAD_ARG;
-    (void)X; (void)y; (void)n; (void)d; (void)thetas; (void)sigmas; (void)B; (void)kernel; (void)nll_out; (void)grad_out; (void)status_out;
-    BADARG("lml_batch: not available in this build");
+    if (!X || !y || !thetas || !sigmas || !nll_out) BADARG("lml_batch: null input");
+    if (n <= 0 || d <= 0 || d > MAX_D || B <= 0) BADARG("lml_batch: need n >= 1, 1 <= d <= 32, B >= 1");
+    if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN52) BADARG("lml_batch: unknown kernel");
+    if (grad_out && kernel != GPBO_KERNEL_RBF) BADARG("lml_batch: the analytic gradient exists for the RBF kernel only");
+    if (grad_out && d > GRAD_D) BADARG("lml_batch: gradient supports d <= 16");
+    for (int64_t i = 0; i < (int64_t)B * d; ++i)
+        if (!(thetas[i] != 0.0) || !std::isfinite(thetas[i])) BADARG("lml_batch: theta entries must be finite and non-zero");
+    for (int b = 0; b < B; ++b)
+        if (!(sigmas[b] >= 0)) BADARG("lml_batch: sigmas must be >= 0");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n_pad = round_up(n, PB);
+    CHK(ensure_model(ctx, n_pad, d, true));
+    ctx->fitted = false;             // the model buffers are reused as work space
+    ctx->have_posterior = false;
+    ctx->have_factor = false;
+    ctx->n = n;
+    ctx->n_pad = n_pad;
+    ctx->nb = n_pad / PB;
+    ctx->d = d;
+    ctx->kernel = kernel;
+    ctx->variant = GPBO_VARIANT_SINGLE;
+    const int nb = (int)ctx->nb;
+    const int ntiles = nb * nb;
+
+    double *Xraw = nullptr, *th_dev = nullptr, *onll = nullptr, *ograd = nullptr, *gpart = nullptr;
+    int* infos = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)Xraw, (void*)th_dev, (void*)onll, (void*)ograd, (void*)gpart, (void*)infos})
+            if (p) hipFree(p);
+    };
+#define LCHK(expr)                                                    \
+    do {                                                              \
+        hipError_t e_ = (expr);                                       \
+        if (e_ != hipSuccess) {                                       \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_); \
+            cleanup();                                                \
+            return GPBO_ERR_HIP;                                      \
+        }                                                             \
+    } while (0)
+    LCHK(hipMalloc((void**)&Xraw, (size_t)d * n_pad * 8));
+    LCHK(hipMalloc((void**)&th_dev, (size_t)B * d * 8));
+    LCHK(hipMalloc((void**)&onll, (size_t)B * 8));
+    LCHK(hipMalloc((void**)&ograd, (size_t)B * d * 8));
+    LCHK(hipMalloc((void**)&gpart, (size_t)ntiles * GRAD_D * 8));
+    LCHK(hipMalloc((void**)&infos, (size_t)B * sizeof(int)));
+    {
+        std::vector<double> xr((size_t)d * n_pad, 0.0), yp(n_pad, 0.0);
+        for (int t = 0; t < d; ++t)
+            for (int64_t i = 0; i < n; ++i) xr[(size_t)t * n_pad + i] = X[i * d + t];
+        for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
+        LCHK(hipMemcpy(Xraw, xr.data(), xr.size() * 8, hipMemcpyHostToDevice));
+        LCHK(hipMemcpy(ctx->yv, yp.data(), yp.size() * 8, hipMemcpyHostToDevice));
+        LCHK(hipMemcpy(th_dev, thetas, (size_t)B * d * 8, hipMemcpyHostToDevice));
+        LCHK(hipMemsetAsync(infos, 0, (size_t)B * sizeof(int), ctx->stream));
+    }
+    timing_begin(ctx);
+    {
+        Scope tot(ctx, T_TOTAL);
+        for (int b = 0; b < B; ++b) {
+            const double eps = (sigmas[b] == 0) ? 1e-15 * (double)n : sigmas[b] * sigmas[b];
+            hipLaunchKernelGGL(k_setup_setting, dim3((unsigned)((n_pad + 255) / 256), (unsigned)d), dim3(256), 0, ctx->stream,
+                               (const double*)Xraw, (const double*)(th_dev + (size_t)b * d), (int)d, (int)n_pad, ctx->Xts, ctx->params);
+            int st = launch_kernel_matrix(ctx, ctx->bufA, nullptr, eps);
+            if (st == GPBO_OK) st = launch_cholesky(ctx, ctx->bufA, infos + b);
+            if (st == GPBO_OK) st = launch_trsv(ctx, ctx->bufA);
+            if (st != GPBO_OK) {
+                cleanup();
+                return st;
+            }
+            hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bufA, (long)n_pad,
+                               (const double*)ctx->yv, (const double*)ctx->alpha1, ctx->alpha, (int)n, (int)n_pad,
+                               (int)GPBO_VARIANT_SINGLE, ctx->params);
+            if (grad_out) {
+                st = launch_inverse(ctx, ctx->bufA, ctx->bufW, ctx->bufB);
+                if (st != GPBO_OK) {
+                    cleanup();
+                    return st;
+                }
+                hipMemsetAsync(gpart, 0, (size_t)ntiles * GRAD_D * 8, ctx->stream);
+                hipLaunchKernelGGL(k_lml_grad_tiles, dim3(nb, nb), dim3(GEMM_THREADS), 0, ctx->stream, (const double*)ctx->bufW,
+                                   (long)n_pad, (const double*)ctx->Xts, (int)n, (int)n_pad, (int)d, (const double*)ctx->alpha1,
+                                   (const double*)ctx->params, gpart, nb);
+            }
+            hipLaunchKernelGGL(k_lml_store, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->params,
+                               (const int*)(infos + b), (const double*)gpart, ntiles, (int)d, grad_out ? 1 : 0, onll + b,
+                               ograd + (size_t)b * d);
+        }
+    }
+    LCHK(hipGetLastError());
+    std::vector<int> hinfo(B);
+    LCHK(hipMemcpyAsync(nll_out, onll, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (grad_out) LCHK(hipMemcpyAsync(grad_out, ograd, (size_t)B * d * 8, hipMemcpyDeviceToHost, ctx->stream));
+    LCHK(hipMemcpyAsync(hinfo.data(), infos, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    LCHK(hipStreamSynchronize(ctx->stream));
+#undef LCHK
+    double ms[T_NCAT], cnt[T_NCAT];
+    timing_collect(ctx, ms, cnt);
+    ctx->tm.fit_total_ms = ms[T_TOTAL];
+    ctx->tm.kbuild_ms = ms[T_KBUILD];
+    ctx->tm.chol_ms = ms[T_CHOL];
+    ctx->tm.chol_count = B;
+    ctx->tm.trsv_ms = ms[T_TRSV];
+    ctx->tm.inverse_ms = ms[T_INV];
+    for (int b = 0; b < B; ++b) {
+        const bool bad = hinfo[b] != 0 || !std::isfinite(nll_out[b]);
+        if (status_out) status_out[b] = bad ? GPBO_ERR_NOT_PD : GPBO_OK;
+        if (bad) nll_out[b] = NAN;
+    }
+    cleanup();
+    return GPBO_OK;
 }
 
 }  // extern "C"

@@ -386,9 +386,13 @@ __global__ __launch_bounds__(256) void k_ks_build(const double* __restrict__ Xs,
 
 // V = W * Bmat (W lower triangular), fused epilogue: per-column sum of squares of the
 // 128 rows of the tile -> partial[ib][j].  Tiles are issued heaviest (largest ib) first.
+// STORE_V: also keep V rows < v_rows of the tile in the resident buffer Vres[row][j0 + col]
+// (row pitch ldv = number of candidates) for the incremental append path.
+template <bool STORE_V>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __restrict__ W, long ld,
                                                              const double* __restrict__ Bmat, long ldb,
-                                                             double* __restrict__ partial, int nb, int nj) {
+                                                             double* __restrict__ partial, int nb, int nj,
+                                                             double* __restrict__ Vres, long ldv, long j0, long m, int v_rows) {
     __shared__ double lds[GEMM_LDS_DOUBLES];
     const int bid = blockIdx.x;
     const int ib = nb - 1 - bid / nj;
@@ -398,6 +402,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __
     gemm_tile_128<true, false>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
+    if (STORE_V) {
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = ib * PB + acc_row(ta, r);
+                    const long col = j0 + (long)jb * TN + acc_col(tb);
+                    if (row < v_rows && col < m) Vres[(long)row * ldv + col] = acc[ta][tb][r];
+                }
+    }
     double cs[4];
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) {
@@ -422,7 +438,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __
 // var = c0 - c1 * sum_ib partial[ib][j] (clamped: < 1e-60 -> 0), mu = sum_kc mupart[kc][j].
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, const double* __restrict__ mupart,
                                                   long ldb, int nb, int nkc, const double* __restrict__ params,
-                                                  double* __restrict__ mu, double* __restrict__ var, long j0, long m) {
+                                                  double* __restrict__ mu, double* __restrict__ var, long j0, long m,
+                                                  double* __restrict__ sres) {
     const long jl = (long)blockIdx.x * 256 + threadIdx.x;
     const long j = j0 + jl;
     if (jl >= ldb || j >= m) return;
@@ -434,6 +451,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
     if (v < 1e-60) v = 0.0;
     mu[j] = mm;
     var[j] = v;
+    if (sres) sres[j] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -516,6 +534,256 @@ __global__ __launch_bounds__(256) void k_acquire(const double* __restrict__ mu, 
         r = ndtr_dev((mu[j] - *inc_ptr) / sigma);
     }
     out[j] = r;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Batched likelihood sweep helpers.
+// Per setting: Xts[t][i] = Xraw[t][i] / theta[t], params[P_INVTHETA + t] = 1 / theta[t].
+__global__ __launch_bounds__(256) void k_setup_setting(const double* __restrict__ Xraw, const double* __restrict__ theta,
+                                                       int d, int n_pad, double* __restrict__ Xts, double* __restrict__ params) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    const double it = 1.0 / theta[t];
+    if (i < n_pad) Xts[(long)t * n_pad + i] = Xraw[(long)t * n_pad + i] * it;
+    if (i == 0) params[P_INVTHETA + t] = it;
+}
+
+// Gradient of -logL w.r.t. theta (RBF):  g_t = -1/2 sum_{j,k} c_jk dK_t[j][k],
+//   c_jk = n a_j a_k / (y.a) - Kinv_jk,  Kinv = W^T W,  dK_t[j][k] = q_t K0_jk / theta_t,
+//   q_t = ((x_jt - x_kt)/theta_t)^2.
+// One workgroup = one lower tile (jb >= kb) of Kinv on the MFMA tile engine, reduced against dK_t
+// in the epilogue without ever storing Kinv.  gpart[(jb*nb + kb)*GRAD_D + t] = sum_tile c_jk q_t K0_jk
+// (x2 for off-diagonal tiles); the caller zero-fills gpart.
+constexpr int GRAD_D = 16;
+__global__ __launch_bounds__(GEMM_THREADS) void k_lml_grad_tiles(const double* __restrict__ W, long ld,
+                                                                 const double* __restrict__ Xts, int n, int n_pad, int d,
+                                                                 const double* __restrict__ alpha1,
+                                                                 const double* __restrict__ params,
+                                                                 double* __restrict__ gpart, int nb) {
+    const int jb = blockIdx.y, kb = blockIdx.x;
+    if (kb > jb) return;
+    __shared__ double lds[GEMM_LDS_DOUBLES];
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    // A(j, r) = W[r][jb*128 + j], B(r, k) = W[r][kb*128 + k]; W[r][j] = 0 for r < j
+    gemm_tile_128<false, false>(W + (long)jb * PB, ld, W + (long)kb * PB, ld, jb * PB, n_pad, acc, lds);
+    const double scale_c = (double)n / params[P_YA];
+    double g[GRAD_D];
+#pragma unroll
+    for (int t = 0; t < GRAD_D; ++t) g[t] = 0.0;
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        const int k = kb * PB + acc_col(tb);
+        double xk[GRAD_D];
+#pragma unroll
+        for (int t = 0; t < GRAD_D; ++t) xk[t] = (t < d) ? Xts[(long)t * n_pad + k] : 0.0;
+        const double ak = alpha1[k];
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jb * PB + acc_row(ta, r);
+                if (j < n && k < n && j != k) {
+                    double q[GRAD_D];
+                    double Dq = 0.0;
+#pragma unroll
+                    for (int t = 0; t < GRAD_D; ++t) {
+                        const double df = (t < d) ? Xts[(long)t * n_pad + j] - xk[t] : 0.0;
+                        q[t] = df * df;
+                        Dq += q[t];
+                    }
+                    const double c = (scale_c * alpha1[j] * ak - acc[ta][tb][r]) * exp(-0.5 * Dq);
+#pragma unroll
+                    for (int t = 0; t < GRAD_D; ++t) g[t] += c * q[t];
+                }
+            }
+    }
+    const double wgt = (jb == kb) ? 1.0 : 2.0;
+    double* red = lds;   // tile engine ended on a barrier
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < GRAD_D; ++t) {
+        double v = g[t];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) red[(tid >> 6) * GRAD_D + t] = v;
+    }
+    __syncthreads();
+    if (tid < GRAD_D)
+        gpart[((long)jb * nb + kb) * GRAD_D + tid] = wgt * (red[tid] + red[GRAD_D + tid] + red[2 * GRAD_D + tid] + red[3 * GRAD_D + tid]);
+}
+
+// out_nll[b] = -logL (NaN when the factorisation failed), out_grad[b*d + t] = -1/2 * sum_tiles gpart / theta_t
+__global__ __launch_bounds__(256) void k_lml_store(const double* __restrict__ params, const int* __restrict__ info,
+                                                   const double* __restrict__ gpart, int ntiles, int d, int want_grad,
+                                                   double* __restrict__ out_nll, double* __restrict__ out_grad) {
+    __shared__ double r[256];
+    const int tid = threadIdx.x;
+    const bool bad = (*info != 0);
+    if (tid == 0) *out_nll = bad ? NAN : params[P_NLL];
+    if (!want_grad) return;
+    for (int t = 0; t < d; ++t) {
+        double s = 0.0;
+        for (int i = tid; i < ntiles; i += 256) s += gpart[(long)i * GRAD_D + t];
+        r[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) r[tid] += r[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) out_grad[t] = bad ? NAN : -0.5 * r[0] * params[P_INVTHETA + t];
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Incremental append of one training point (single-factor variant, theta frozen).
+// scal (device doubles): [0] d_new  [1] z_new  [2] ll = l.l  [3] lz = l.z
+enum { A_DNEW = 0, A_ZNEW = 1, A_LL = 2, A_LZ = 3 };
+
+// kvec[i] = k(x_i, x_new) for i < n (0 for the pad); also records the new scaled point as column n of Xts.
+__global__ __launch_bounds__(256) void k_append_kvec(double* __restrict__ Xts, int n, int n_pad, int d,
+                                                     const double* __restrict__ xnew, double* __restrict__ kvec, int kernel) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    double v = 0.0;
+    if (i < n) {
+        double Dq = 0.0;
+        for (int t = 0; t < d; ++t) {
+            const double df = Xts[(long)t * n_pad + i] - xnew[t];
+            Dq += df * df;
+        }
+        v = kern_eval(Dq, kernel);
+    }
+    kvec[i] = v;
+    if (i == n)
+        for (int t = 0; t < d; ++t) Xts[(long)t * n_pad + n] = xnew[t];
+}
+
+// l = W[0:n,0:n] * kvec  (one wave per row, lanes along the row)
+__global__ __launch_bounds__(256) void k_append_lvec(const double* __restrict__ W, long ld, int n, const double* __restrict__ kvec,
+                                                     double* __restrict__ lvec) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double s = 0.0;
+    for (int j = lane; j <= row; j += 64) s += W[(long)row * ld + j] * kvec[j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) lvec[row] = s;
+}
+
+// One workgroup: d_new = sqrt(1 + eps - l.l), z_new = (y_new - l.z)/d_new, scalars of the enlarged model,
+// new rows of L (optional) and the diagonal of W.  n is the size BEFORE the append.
+__global__ __launch_bounds__(256) void k_append_scalars(const double* __restrict__ lvec, double* __restrict__ zfw,
+                                                        double* __restrict__ yv, int n, double y_new, double eps,
+                                                        double* __restrict__ scal, double* __restrict__ params,
+                                                        double* __restrict__ L, double* __restrict__ W, long ld,
+                                                        int* __restrict__ info) {
+    __shared__ double r1[256];
+    __shared__ double r2[256];
+    const int tid = threadIdx.x;
+    double ll = 0.0, lz = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        ll += lvec[i] * lvec[i];
+        lz += lvec[i] * zfw[i];
+    }
+    r1[tid] = ll;
+    r2[tid] = lz;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            r1[tid] += r1[tid + o];
+            r2[tid] += r2[tid + o];
+        }
+        __syncthreads();
+    }
+    const double dd = 1.0 + eps - r1[0];
+    const double dnew = sqrt(dd);
+    const double znew = (y_new - r2[0]) / dnew;
+    if (L)
+        for (int i = tid; i < n; i += 256) L[(long)n * ld + i] = lvec[i];
+    if (tid == 0) {
+        if (!(dd > 0.0)) atomicCAS(info, 0, n + 1);
+        scal[A_DNEW] = dnew;
+        scal[A_ZNEW] = znew;
+        scal[A_LL] = r1[0];
+        scal[A_LZ] = r2[0];
+        zfw[n] = znew;
+        yv[n] = y_new;
+        if (L) L[(long)n * ld + n] = dnew;
+        W[(long)n * ld + n] = 1.0 / dnew;
+        const int n1 = n + 1;
+        const double ya = params[P_YA] + znew * znew;          // y^T K^-1 y = |L^-1 y|^2
+        const double sumlog = params[P_SUMLOG] + log(dnew);
+        const double theta1 = ya / n1;
+        params[P_YA] = ya;
+        params[P_SUMLOG] = sumlog;
+        params[P_THETA1] = theta1;
+        params[P_C0] = theta1;
+        params[P_C1] = theta1;
+        params[P_YMAX] = fmax(params[P_YMAX], y_new);
+        params[P_NLL] = 0.5 * n1 * (log(2.0 * M_PI) + 1.0) + 0.5 * n1 * log(theta1) + sumlog;
+    }
+}
+
+// New row of W: W[n][j] = -(1/d_new) * sum_{i>=j} l_i W[i][j]  (thread per column, coalesced), j < n.
+__global__ __launch_bounds__(256) void k_append_wrow(double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
+                                                     const double* __restrict__ scal) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int i = j; i < n; ++i) s += lvec[i] * W[(long)i * ld + j];
+    W[(long)n * ld + j] = -s / scal[A_DNEW];
+}
+
+// alpha1 = W^T z over the enlarged model (n1 rows); alpha (used for the mean) = alpha1 for this variant.
+__global__ __launch_bounds__(256) void k_append_alpha(const double* __restrict__ W, long ld, int n1, const double* __restrict__ zfw,
+                                                      double* __restrict__ alpha1, double* __restrict__ alpha) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n1) return;
+    double s = 0.0;
+    for (int i = j; i < n1; ++i) s += W[(long)i * ld + j] * zfw[i];
+    alpha1[j] = s;
+    alpha[j] = s;
+}
+
+// The HBM-streaming sweep: per candidate j
+//   v = (k(xs_j, x_new) - sum_{k<n} l_k V[k][j]) / d_new ;  V[n][j] = v ;  s_j += v^2 ;  mu_j += v z_new ;
+//   var_j = theta1 (1 - s_j), < 1e-60 -> 0.
+template <int D>
+__global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__ Xs, long m, int d_rt,
+                                                      const double* __restrict__ xnew, const double* __restrict__ params,
+                                                      const double* __restrict__ lvec, const double* __restrict__ scal,
+                                                      double* __restrict__ V, long ldv, int n, double* __restrict__ sres,
+                                                      double* __restrict__ mu, double* __restrict__ var, int kernel) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int d = (D > 0) ? D : d_rt;
+    double Dq = 0.0;
+#pragma unroll
+    for (int t = 0; t < ((D > 0) ? D : MAX_D); ++t)
+        if (t < d) {
+            const double df = Xs[j * d + t] * params[P_INVTHETA + t] - xnew[t];
+            Dq += df * df;
+        }
+    double dot0 = 0.0, dot1 = 0.0, dot2 = 0.0, dot3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        dot0 += lvec[k] * V[(long)k * ldv + j];
+        dot1 += lvec[k + 1] * V[(long)(k + 1) * ldv + j];
+        dot2 += lvec[k + 2] * V[(long)(k + 2) * ldv + j];
+        dot3 += lvec[k + 3] * V[(long)(k + 3) * ldv + j];
+    }
+    for (; k < n; ++k) dot0 += lvec[k] * V[(long)k * ldv + j];
+    const double v = (kern_eval(Dq, kernel) - ((dot0 + dot1) + (dot2 + dot3))) / scal[A_DNEW];
+    V[(long)n * ldv + j] = v;
+    const double s = sres[j] + v * v;
+    sres[j] = s;
+    mu[j] += v * scal[A_ZNEW];
+    double vv = params[P_C0] - params[P_C1] * s;
+    if (vv < 1e-60) vv = 0.0;
+    var[j] = vv;
 }
 
 __global__ void k_set_scalar(double* dst, double v) { *dst = v; }

@@ -139,14 +139,23 @@ class GP:
         self.m = m
         return mu, var, ei, int(idx.value), eim.value, mum.value
 
+    def reserve_appends(self, max_appends: int):
+        """Room for appended points; call before fit(variant=VARIANT_SINGLE)."""
+        self._check(self._lib.gpbo_reserve_appends(self._h, int(max_appends)))
+
     def append(self, x_new, y_new):
         x = _f64(np.asarray(x_new).reshape(-1), 1)
         if x.shape[0] != self.d:
             raise ValueError('x_new has %d entries, the model %d columns' % (x.shape[0], self.d))
         mm = C.c_double()
         self._check(self._lib.gpbo_append(self._h, L.dptr(x), float(y_new), C.byref(mm)))
-        self.n += 1
+        self._refresh_scalars()
         return mm.value
+
+    def _refresh_scalars(self):
+        t1, nll, ym, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        self._check(self._lib.gpbo_model_scalars(self._h, C.byref(t1), C.byref(nll), C.byref(ym), C.byref(n)))
+        self.theta1, self.nll, self.y_max, self.n = t1.value, nll.value, ym.value, int(n.value)
 
     def factor(self, want_L=True, want_alpha=True):
         Lm = np.empty((self.n, self.n)) if want_L else None

@@ -64,7 +64,9 @@ typedef struct gpbo_timings {
     double finalize_ms;    /* variance/mean finalisation + max(mu) */
     double acquire_ms;     /* acquisition + argmax */
     double trmm_flops;     /* algorithmic flops of the trmm launches: n_pad-free count n^2 per candidate */
-    double reserved[3];
+    double append_total_ms;  /* last gpbo_append: factor update + sweep + max(mu) */
+    double append_sweep_ms;  /* the HBM-streaming V sweep of the last gpbo_append */
+    double reserved[1];
 } gpbo_timings;
 
 /* Device-side description of a fitted model, for broadcasting it to other ranks
@@ -127,6 +129,10 @@ int gpbo_predict_ei(gpbo_ctx* ctx, const double* Xs, int64_t m, double kappa,
  * posterior for frozen theta (GP/BayesOptFcn_v1.m:73-83). */
 int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out);
 
+/* Room for max_appends appended points; call BEFORE gpbo_fit (single-factor variant).  The next
+ * gpbo_posterior then keeps V = L^-1 Ks^T (rows x candidates, 8 bytes each) resident in HBM. */
+int gpbo_reserve_appends(gpbo_ctx* ctx, int64_t max_appends);
+
 /* -logL (mlefcn, BayesOpt_v4.ipynb:154-165) and, when grad_out != NULL, its gradient
  * w.r.t. theta (jacmlefun, GP/BayesOpt_v3.m:392-417; RBF only) for B settings.
  * thetas is (B,d), sigmas (B,), nll_out (B,), grad_out (B,d).  status_out (B,) may be
@@ -140,6 +146,9 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
 int gpbo_get_factor(gpbo_ctx* ctx, double* L_out, double* alpha_out);
 
 int gpbo_last_timings(gpbo_ctx* ctx, gpbo_timings* out);
+
+/* Scalars of the current model: theta1 (BayesOpt_v4.ipynb:144), -logL (:164), max(yTrain), n.  Any may be NULL. */
+int gpbo_model_scalars(gpbo_ctx* ctx, double* theta1_out, double* nll_out, double* y_max_out, int64_t* n_out);
 
 /* Multi-GPU: rank 0 fits, gpbo_state_describe() exposes the device buffers that the
  * other ranks need; they call gpbo_state_alloc() with the same shape, receive the

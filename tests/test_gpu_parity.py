@@ -215,3 +215,82 @@ def test_model_handoff_to_a_second_context_is_bit_exact(gp0):
     with pytest.raises(ValueError):
         gp1.factor()                      # a received model carries no Cholesky factor
     gp1.close()
+
+
+def test_lml_batch_and_gradient(gp0):
+    """mlefcn on a (theta1, theta2, sigma) batch against the reference's own grid values, and the
+    analytic gradient (MATLAB jacmlefun text) against the oracle's restatement of it."""
+    from bayesian_optimization_amd import GP
+    g = golden('g6_mle_grid')
+    th0 = g['th0']
+    X, y = g['xTrain'], g['yTrain']
+    gpl = GP(0)                                   # a context of its own: the sweep reuses the model buffers as work space
+    thetas = np.array([[a, b] for a in th0[::3] for b in th0[1::4]])
+    for key, s in (('nll_sigma0', 0.0), ('nll_sigma005', 0.05)):
+        ref = np.array([g[key][i, j] for i in range(0, 16, 3) for j in range(1, 16, 4)])
+        nll, stat = gpl.lml_batch(X, y, thetas, np.full(len(thetas), s))
+        ok = stat == 0
+        assert ok.sum() >= len(thetas) - 2
+        if s == 0.0:
+            # sigmaY = 0 with length scales >= 0.3: K + 1e-15*n*I is numerically singular and the reference's own
+            # values are round-off noise at the 1e-4 level; only the well-conditioned corner pins the arithmetic
+            ok &= thetas.max(axis=1) <= 0.2
+            assert ok.sum() >= 1
+        assert np.max(np.abs(nll[ok] - ref[ok]) / np.abs(ref[ok])) <= (1e-8 if s == 0.0 else 1e-10)
+    # gradient, well-conditioned settings
+    pts = np.array([[0.1036165, 0.0995048], [0.3, 0.2], [0.8, 1.1], [0.1036165, 0.0995048]])
+    sig = np.array([0.05, 0.05, 0.05, 0.0])
+    nll, grad, stat = gpl.lml_batch(X, y, pts, sig, grad=True)
+    assert np.all(stat == 0)
+    for i in range(len(pts)):
+        g_o = o.mle_grad(X, y, pts[i], float(sig[i]))
+        assert abs(nll[i] - o.mlefcn(X, y, pts[i], float(sig[i]))) <= 1e-10 * abs(nll[i])
+        assert np.max(np.abs(grad[i] - g_o)) <= 1e-8 * np.max(np.abs(g_o))
+    # larger, d = 8 (two tiles per side, off-diagonal tile weights) + one failing setting in the batch
+    Xb, yb, _ = synth(300, 8, 4, 91)
+    thb = np.vstack([np.full(8, 0.9), np.full(8, 1.3), np.full(8, 400.0)])
+    sgb = np.array([0.1, 0.02, 0.0])
+    nll, grad, stat = gpl.lml_batch(Xb, yb, thb, sgb, grad=True)
+    assert list(stat[:2]) == [0, 0] and stat[2] == 1 and np.isnan(nll[2])
+    for i in range(2):
+        g_o = o.mle_grad(Xb, yb, thb[i], float(sgb[i]))
+        assert abs(nll[i] - o.mlefcn(Xb, yb, thb[i], float(sgb[i]))) <= 1e-10 * abs(nll[i])
+        assert np.max(np.abs(grad[i] - g_o)) <= 1e-8 * np.max(np.abs(g_o))
+    gpl.close()
+
+
+def test_incremental_append_equals_refit(gp0):
+    """theta frozen, single-factor variant: append == refit on the enlarged set (oracle and GPU)."""
+    from bayesian_optimization_amd import GP
+    n0, d, m, k = 120, 3, 5000, 12            # crosses the 128-row pad boundary
+    X, y, Xs = synth(n0 + k, d, m, 17)
+    theta = np.array([0.35, 0.45, 0.55])
+    gpi = GP(0)
+    gpi.reserve_appends(k)
+    gpi.fit(X[:n0], y[:n0], theta, 0.05, variant=bo.VARIANT_SINGLE)
+    gpi.set_candidates(Xs)
+    gpi.posterior()
+    st = o.fit(X[:n0], y[:n0], theta, 0.05, variant=o.VARIANT_SINGLE)
+    for i in range(n0, n0 + k):
+        mu_max = gpi.append(X[i], y[i])
+        st = o.append_point(st, X[i], y[i])
+        mu, var = gpi.read()
+        assert mu_max == np.max(mu)
+    ref = o.fit(X, y, theta, 0.05, variant=o.VARIANT_SINGLE)
+    mu_r, var_r = o.predict(ref, Xs)
+    mu_a, var_a = o.predict(st, Xs)
+    assert relmax(mu, mu_r) <= TOL_MU and relmax(var, var_r) <= TOL_VAR
+    assert relmax(mu, mu_a) <= TOL_MU and relmax(var, var_a) <= TOL_VAR
+    assert gpi.n == n0 + k and abs(gpi.theta1 - ref['theta1']) <= 1e-10 * ref['theta1']
+    assert abs(gpi.nll - ref['nll']) <= 1e-10 * abs(ref['nll'])
+    idx, best = gpi.acquire(bo.ACQ_EI, 0.01)
+    assert idx == int(np.argmax(o.expected_improvement(mu_r, var_r, 0.01)))
+    Lm, al = gpi.factor()
+    assert relmax(Lm, ref['L1']) <= 1e-10 and relmax(al, ref['alpha1']) <= 1e-8
+    # a full recompute from the updated factor agrees with the incrementally updated posterior
+    gpi.posterior()
+    mu2, var2 = gpi.read()
+    assert relmax(mu2, mu) <= 1e-12 and relmax(var2, var) <= 1e-11
+    with pytest.raises(ValueError):
+        gpi.append(X[0], y[0])                 # reserved rows exhausted
+    gpi.close()
