@@ -14,6 +14,8 @@
 #include "../../include/gpbo.h"
 #include "kernels.hpp"
 
+#define GPBO_VARIANT_KRIGING 2   /* trend GP of Gaussian_Process_Regression.ipynb:197-234 (internal tag) */
+
 using namespace gpbo;
 
 namespace {
@@ -57,7 +59,7 @@ struct gpbo_ctx {
 
     // candidates + outputs
     double* Xs = nullptr;
-    int64_t m = 0, m_cap = 0;
+    int64_t m = 0, m_cap = 0, xs_cap = 0;   // m_cap: outputs (doubles per array); xs_cap: doubles in Xs
     double *mu = nullptr, *var = nullptr, *acq = nullptr;
     bool have_posterior = false;
 
@@ -349,7 +351,7 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                 hipLaunchKernelGGL(k_finalize, dim3((unsigned)(cols / 256)), dim3(256), 0, ctx->stream,
                                    (const double*)ctx->partial, (const double*)ctx->mupart, (long)ctx->chunk, nb, nkc,
                                    (const double*)ctx->params, ctx->mu, ctx->var, (long)j0, (long)ctx->m,
-                                   keep_v ? ctx->sres : (double*)nullptr);
+                                   keep_v ? ctx->sres : (double*)nullptr, (const double*)ctx->Xs, ctx->d);
             }
         }
         {
@@ -490,8 +492,11 @@ int acquire_impl(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumben
 int set_candidates_impl(gpbo_ctx* ctx, const double* Xs, int64_t m, int on_device) {
     if (!Xs || m <= 0) BADARG("set_candidates: empty candidate set");
     if (!ctx->fitted) BADARG("set_candidates: fit first (the candidate width is the model's d)");
-    if (m > ctx->m_cap) {
+    if (m * ctx->d > ctx->xs_cap) {
         CHK(dev_alloc(ctx, &ctx->Xs, (size_t)m * ctx->d));
+        ctx->xs_cap = m * ctx->d;
+    }
+    if (m > ctx->m_cap) {
         CHK(dev_alloc(ctx, &ctx->mu, m));
         CHK(dev_alloc(ctx, &ctx->var, m));
         CHK(dev_alloc(ctx, &ctx->acq, m));
@@ -796,6 +801,244 @@ int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max
     if (!ctx) return GPBO_ERR_BAD_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     return append_impl(ctx, x_new, y_new, mu_max_out);
+}
+
+int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, double theta, int32_t deg,
+                     double* beta_out, int32_t* nbeta_out, double* cov_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!X || !y) BADARG("kriging_fit: null input");
+    if (n <= 0 || d <= 0 || d > 3) BADARG("kriging_fit: the trend basis exists for 1..3 input columns");
+    if (deg < 0) BADARG("kriging_fit: negative degree");
+    if (!(theta != 0.0) || !std::isfinite(theta)) BADARG("kriging_fit: theta must be finite and non-zero");
+    // number of trend columns, as polymat builds them
+    int p = 1;
+    if (deg >= 1) p = 1 + d;
+    if (deg >= 2) p = 1 + 2 * d;
+    if (deg >= 3 && d == 2) p = 6;
+    if (deg >= 3 && d == 3) p = 10;
+    if (n < p) BADARG("kriging_fit: fewer training points than trend columns");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n_pad = round_up(n, PB);
+    CHK(ensure_model(ctx, n_pad, d, true));
+    ctx->fitted = false;
+    ctx->have_posterior = false;
+    ctx->inc_valid = false;
+    ctx->n = n;
+    ctx->n_pad = n_pad;
+    ctx->nb = n_pad / PB;
+    ctx->d = d;
+    ctx->kernel = GPBO_KERNEL_RBF;
+    ctx->variant = GPBO_VARIANT_KRIGING;
+    ctx->sigmaY = 0;
+    ctx->eps = 0.0;                          // gpr_poly uses K as built, no jitter (:199-202)
+    ctx->theta.assign(d, theta);
+    ctx->info = 0;
+    const int q = p + 1;                     // right-hand sides: the p trend columns and y
+    std::vector<double> xts((size_t)d * n_pad, 0.0), par(PARAMS_DOUBLES, 0.0), rhs((size_t)q * n_pad, 0.0);
+    for (int t = 0; t < d; ++t) {
+        par[P_INVTHETA + t] = 1.0 / theta;
+        for (int64_t i = 0; i < n; ++i) xts[(size_t)t * n_pad + i] = X[i * d + t] / theta;
+    }
+    auto trend_col = [&](int64_t i, int c) -> double {
+        const double* x = X + i * d;
+        if (c == 0) return 1.0;
+        if (c <= d) return x[c - 1];
+        if (c <= 2 * d) return x[c - 1 - d] * x[c - 1 - d];
+        if (d == 2) return x[0] * x[1];
+        const int pair = c - 1 - 2 * d;     // d == 3: xy, xz, yz
+        return pair == 0 ? x[0] * x[1] : (pair == 1 ? x[0] * x[2] : x[1] * x[2]);
+    };
+    for (int c = 0; c < p; ++c)
+        for (int64_t i = 0; i < n; ++i) rhs[(size_t)c * n_pad + i] = trend_col(i, c);
+    for (int64_t i = 0; i < n; ++i) rhs[(size_t)p * n_pad + i] = y[i];
+    double *rhs_dev = nullptr, *u_dev = nullptr, *x_dev = nullptr;
+    auto cleanup = [&]() {
+        for (void* ptr : {(void*)rhs_dev, (void*)u_dev, (void*)x_dev})
+            if (ptr) hipFree(ptr);
+    };
+    if (hipMalloc((void**)&rhs_dev, rhs.size() * 8) != hipSuccess || hipMalloc((void**)&u_dev, rhs.size() * 8) != hipSuccess ||
+        hipMalloc((void**)&x_dev, rhs.size() * 8) != hipSuccess) {
+        cleanup();
+        ctx->err = "kriging_fit: hipMalloc failed";
+        return GPBO_ERR_HIP;
+    }
+    hipMemcpyAsync(ctx->Xts, xts.data(), xts.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(ctx->params, par.data(), par.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(rhs_dev, rhs.data(), rhs.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    timing_begin(ctx);
+    int st = GPBO_OK;
+    {
+        Scope tot(ctx, T_TOTAL);
+        st = launch_kernel_matrix(ctx, ctx->bufA, nullptr, 0.0);
+        if (st == GPBO_OK) st = launch_cholesky(ctx, ctx->bufA, ctx->info_dev);
+        if (st == GPBO_OK) st = launch_inverse(ctx, ctx->bufA, ctx->bufW, ctx->bufB);
+        if (st == GPBO_OK) {
+            hipLaunchKernelGGL(k_tri_gemv_n, dim3((unsigned)((n + 3) / 4), (unsigned)q), dim3(256), 0, ctx->stream,
+                               (const double*)ctx->bufW, (long)n_pad, (int)n, (const double*)rhs_dev, u_dev, (int)n_pad);
+            hipLaunchKernelGGL(k_tri_gemv_t, dim3((unsigned)((n + 255) / 256), (unsigned)q), dim3(256), 0, ctx->stream,
+                               (const double*)ctx->bufW, (long)n_pad, (int)n, (const double*)u_dev, x_dev, (int)n_pad);
+        }
+    }
+    if (st != GPBO_OK) {
+        cleanup();
+        return st;
+    }
+    std::vector<double> sol((size_t)q * n_pad);
+    int info = 0;
+    hipError_t e1 = hipMemcpyAsync(sol.data(), x_dev, sol.size() * 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e3 = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        ctx->err = "kriging_fit: device copy failed";
+        return GPBO_ERR_HIP;
+    }
+    double ms[T_NCAT], cnt[T_NCAT];
+    timing_collect(ctx, ms, cnt);
+    ctx->tm.fit_total_ms = ms[T_TOTAL];
+    ctx->tm.kbuild_ms = ms[T_KBUILD];
+    ctx->tm.chol_ms = ms[T_CHOL];
+    ctx->tm.chol_count = 1;
+    ctx->tm.inverse_ms = ms[T_INV];
+    if (info != 0) {
+        ctx->info = info;
+        ctx->err = "kriging_fit: K is not positive definite (no jitter is added in this flavour)";
+        return GPBO_ERR_NOT_PD;
+    }
+    // GLS trend on the host (p <= 10): beta = (F^T K^-1 F)^-1 F^T K^-1 y, :201
+    std::vector<double> A((size_t)p * p), b(p), beta(p);
+    for (int r = 0; r < p; ++r) {
+        for (int c = 0; c < p; ++c) {
+            double s2 = 0;
+            for (int64_t i = 0; i < n; ++i) s2 += rhs[(size_t)r * n_pad + i] * sol[(size_t)c * n_pad + i];
+            A[(size_t)r * p + c] = s2;
+        }
+        double s3 = 0;
+        for (int64_t i = 0; i < n; ++i) s3 += rhs[(size_t)r * n_pad + i] * sol[(size_t)p * n_pad + i];
+        b[r] = s3;
+    }
+    {   // Gaussian elimination with partial pivoting (what np.linalg.solve does for this p x p system)
+        std::vector<int> piv(p);
+        for (int c = 0; c < p; ++c) {
+            int best = c;
+            for (int r = c + 1; r < p; ++r)
+                if (std::fabs(A[(size_t)r * p + c]) > std::fabs(A[(size_t)best * p + c])) best = r;
+            if (A[(size_t)best * p + c] == 0.0) {
+                ctx->err = "kriging_fit: singular trend system F^T K^-1 F";
+                return GPBO_ERR_NOT_PD;
+            }
+            if (best != c) {
+                for (int k2 = 0; k2 < p; ++k2) std::swap(A[(size_t)c * p + k2], A[(size_t)best * p + k2]);
+                std::swap(b[c], b[best]);
+            }
+            for (int r = c + 1; r < p; ++r) {
+                const double f = A[(size_t)r * p + c] / A[(size_t)c * p + c];
+                for (int k2 = c; k2 < p; ++k2) A[(size_t)r * p + k2] -= f * A[(size_t)c * p + k2];
+                b[r] -= f * b[c];
+            }
+        }
+        for (int r = p - 1; r >= 0; --r) {
+            double s2 = b[r];
+            for (int c = r + 1; c < p; ++c) s2 -= A[(size_t)r * p + c] * beta[c];
+            beta[r] = s2 / A[(size_t)r * p + r];
+        }
+    }
+    // a = K^-1 (y - F beta), cov = (y - F beta)^T a / n  (:202)
+    std::vector<double> a(n_pad, 0.0);
+    double cov = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double ai = sol[(size_t)p * n_pad + i], ri = y[i];
+        for (int c = 0; c < p; ++c) {
+            ai -= sol[(size_t)c * n_pad + i] * beta[c];
+            ri -= rhs[(size_t)c * n_pad + i] * beta[c];
+        }
+        a[i] = ai;
+        cov += ri * ai;
+    }
+    cov /= (double)n;
+    par[P_THETA1] = cov;
+    par[P_CB] = 1.0;
+    par[P_C0] = cov * cov;                   // mse = cov**2 * (1 - r^T K^-1 r), :233
+    par[P_C1] = cov * cov;
+    par[P_CLAMP] = 0.0;                      // y_kriging_v2 does not clamp
+    par[P_NBETA] = p;
+    par[P_DEG] = deg;
+    double ymax = y[0];
+    for (int64_t i = 1; i < n; ++i) ymax = std::max(ymax, y[i]);
+    par[P_YMAX] = ymax;
+    for (int c = 0; c < p; ++c) par[P_BETA + c] = beta[c];
+    HIPCHK(hipMemcpy(ctx->params, par.data(), par.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->alpha, a.data(), a.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->alpha1, a.data(), a.size() * 8, hipMemcpyHostToDevice));
+    ctx->theta1 = cov;
+    ctx->nll = NAN;
+    ctx->y_max = ymax;
+    ctx->bufL = ctx->bufA;
+    ctx->fitted = true;
+    ctx->have_factor = true;
+    ctx->reserve_left = 0;
+    if (beta_out) memcpy(beta_out, beta.data(), p * sizeof(double));
+    if (nbeta_out) *nbeta_out = p;
+    if (cov_out) *cov_out = cov;
+    return GPBO_OK;
+}
+
+int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64_t m) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!mu || !var || m <= 0) BADARG("set_posterior: empty input");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (m > ctx->m_cap) {
+        CHK(dev_alloc(ctx, &ctx->mu, m));
+        CHK(dev_alloc(ctx, &ctx->var, m));
+        CHK(dev_alloc(ctx, &ctx->acq, m));
+        ctx->m_cap = m;
+    }
+    ctx->m = m;
+    ctx->inc_valid = false;
+    HIPCHK(hipMemcpyAsync(ctx->mu, mu, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->var, var, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+    CHK(reduce_max(ctx, ctx->mu, m, ctx->inc_dev + 1));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->have_posterior = true;
+    return GPBO_OK;
+}
+
+int gpbo_kernel_matrix(gpbo_ctx* ctx, const double* U, int64_t p, const double* V, int64_t q, int32_t d, const double* theta,
+                       int32_t kernel, double* K_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!U || !V || !theta || !K_out || p <= 0 || q <= 0 || d <= 0 || d > MAX_D) BADARG("kernel_matrix: bad arguments");
+    if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN52) BADARG("kernel_matrix: unknown kernel");
+    for (int t = 0; t < d; ++t)
+        if (!(theta[t] != 0.0) || !std::isfinite(theta[t])) BADARG("kernel_matrix: theta entries must be finite and non-zero");
+    HIPCHK(hipSetDevice(ctx->device));
+    double *du = nullptr, *dv = nullptr, *dk = nullptr, *dth = nullptr;
+    auto cleanup = [&]() {
+        for (void* ptr : {(void*)du, (void*)dv, (void*)dk, (void*)dth})
+            if (ptr) hipFree(ptr);
+    };
+    std::vector<double> ith(d);
+    for (int t = 0; t < d; ++t) ith[t] = 1.0 / theta[t];
+    if (hipMalloc((void**)&du, (size_t)p * d * 8) != hipSuccess || hipMalloc((void**)&dv, (size_t)q * d * 8) != hipSuccess ||
+        hipMalloc((void**)&dk, (size_t)p * q * 8) != hipSuccess || hipMalloc((void**)&dth, (size_t)d * 8) != hipSuccess) {
+        cleanup();
+        ctx->err = "kernel_matrix: hipMalloc failed";
+        return GPBO_ERR_HIP;
+    }
+    hipMemcpyAsync(du, U, (size_t)p * d * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(dv, V, (size_t)q * d * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(dth, ith.data(), (size_t)d * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipLaunchKernelGGL(k_cross_kernel, dim3((unsigned)((q + 63) / 64), (unsigned)((p + 3) / 4)), dim3(256), 0, ctx->stream,
+                       (const double*)du, (long)p, (const double*)dv, (long)q, (int)d, (const double*)dth, kernel, dk);
+    hipError_t e1 = hipMemcpyAsync(K_out, dk, (size_t)p * q * 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        ctx->err = std::string("kernel_matrix: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
+        return GPBO_ERR_HIP;
+    }
+    return GPBO_OK;
 }
 
 int gpbo_reserve_appends(gpbo_ctx* ctx, int64_t max_appends) {

@@ -14,8 +14,10 @@ constexpr int PB = 128;    // Cholesky panel / diagonal block
 constexpr int PLD = 130;   // LDS row pitch of the diagonal block (conflict-free pairs)
 
 // params block on the device (doubles)
-enum { P_THETA1 = 0, P_CB = 1, P_C0 = 2, P_C1 = 3, P_NLL = 4, P_YA = 5, P_SUMLOG = 6, P_YMAX = 7, P_INVTHETA = 8 };
-constexpr int PARAMS_DOUBLES = 8 + 32;
+enum { P_THETA1 = 0, P_CB = 1, P_C0 = 2, P_C1 = 3, P_NLL = 4, P_YA = 5, P_SUMLOG = 6, P_YMAX = 7, P_INVTHETA = 8,
+       P_BETA = 40, P_NBETA = 52, P_DEG = 53, P_CLAMP = 54 };
+constexpr int PARAMS_DOUBLES = 64;
+constexpr int MAX_TREND = 10;
 constexpr int MAX_D = 32;
 
 __device__ __forceinline__ double kern_eval(double D, int kernel) {
@@ -331,6 +333,9 @@ __global__ __launch_bounds__(256) void k_fit_scalars(const double* __restrict__ 
         params[P_THETA1] = theta1;
         params[P_YMAX] = r3[0];
         params[P_NLL] = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(theta1) + r2[0];
+        params[P_CLAMP] = 1.0;
+        params[P_NBETA] = 0.0;
+        params[P_DEG] = 0.0;
         if (variant == 0) {
             params[P_CB] = theta1;
             params[P_C0] = theta1;
@@ -435,11 +440,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __
     if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
 }
 
-// var = c0 - c1 * sum_ib partial[ib][j] (clamped: < 1e-60 -> 0), mu = sum_kc mupart[kc][j].
+// Trend basis of the kriging flavour (polymat, Gaussian_Process_Regression.ipynb:113-140): columns for
+// C = 1..3 inputs and degree 0..3, in the reference's column order.  Returns f(x) . beta.
+__device__ __forceinline__ double trend_eval(const double* __restrict__ x, int C, int deg, const double* __restrict__ beta) {
+    double f = beta[0];
+    if (deg == 0) return f;
+    if (C == 1) {
+        f += beta[1] * x[0];
+        if (deg >= 2) f += beta[2] * x[0] * x[0];
+    } else if (C == 2) {
+        f += beta[1] * x[0] + beta[2] * x[1];
+        if (deg >= 2) f += beta[3] * x[0] * x[0] + beta[4] * x[1] * x[1];
+        if (deg >= 3) f += beta[5] * x[0] * x[1];
+    } else {
+        f += beta[1] * x[0] + beta[2] * x[1] + beta[3] * x[2];
+        if (deg >= 2) f += beta[4] * x[0] * x[0] + beta[5] * x[1] * x[1] + beta[6] * x[2] * x[2];
+        if (deg >= 3) f += beta[7] * x[0] * x[1] + beta[8] * x[0] * x[2] + beta[9] * x[1] * x[2];
+    }
+    return f;
+}
+
+// var = c0 - c1 * sum_ib partial[ib][j] (clamped: < 1e-60 -> 0 unless the model says otherwise),
+// mu = sum_kc mupart[kc][j] (+ trend for the kriging flavour).
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, const double* __restrict__ mupart,
                                                   long ldb, int nb, int nkc, const double* __restrict__ params,
                                                   double* __restrict__ mu, double* __restrict__ var, long j0, long m,
-                                                  double* __restrict__ sres) {
+                                                  double* __restrict__ sres, const double* __restrict__ Xs, int d) {
     const long jl = (long)blockIdx.x * 256 + threadIdx.x;
     const long j = j0 + jl;
     if (jl >= ldb || j >= m) return;
@@ -448,7 +474,13 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
     double mm = 0.0;
     for (int c = 0; c < nkc; ++c) mm += mupart[(long)c * ldb + jl];
     double v = params[P_C0] - params[P_C1] * s;
-    if (v < 1e-60) v = 0.0;
+    if (params[P_CLAMP] != 0.0 && v < 1e-60) v = 0.0;
+    const int nbeta = (int)params[P_NBETA];
+    if (nbeta > 0) {
+        double x[3] = {0.0, 0.0, 0.0};
+        for (int t = 0; t < d && t < 3; ++t) x[t] = Xs[j * d + t];
+        mm += trend_eval(x, d, (int)params[P_DEG], params + P_BETA);
+    }
     mu[j] = mm;
     var[j] = v;
     if (sres) sres[j] = s;
@@ -784,6 +816,46 @@ __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__
     double vv = params[P_C0] - params[P_C1] * s;
     if (vv < 1e-60) vv = 0.0;
     var[j] = vv;
+}
+
+
+// u = W v  (lower-triangular W, wave per row) and x = W^T u (thread per column), for q vectors stored
+// column-after-column with pitch n_pad:  K^-1 v = W^T (W v).
+__global__ __launch_bounds__(256) void k_tri_gemv_n(const double* __restrict__ W, long ld, int n, const double* __restrict__ v,
+                                                    double* __restrict__ u, int n_pad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.y;
+    if (row >= n) return;
+    double s = 0.0;
+    for (int j = lane; j <= row; j += 64) s += W[(long)row * ld + j] * v[(long)q * n_pad + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) u[(long)q * n_pad + row] = s;
+}
+__global__ __launch_bounds__(256) void k_tri_gemv_t(const double* __restrict__ W, long ld, int n, const double* __restrict__ u,
+                                                    double* __restrict__ x, int n_pad) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int q = blockIdx.y;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int i = j; i < n; ++i) s += W[(long)i * ld + j] * u[(long)q * n_pad + i];
+    x[(long)q * n_pad + j] = s;
+}
+
+
+// K[i][j] = k(U_i, V_j) for two arbitrary point sets (row-major (p,d), (q,d)); direct differences.
+__global__ __launch_bounds__(256) void k_cross_kernel(const double* __restrict__ U, long p, const double* __restrict__ V, long q,
+                                                      int d, const double* __restrict__ invtheta, int kernel,
+                                                      double* __restrict__ K) {
+    const long j = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const long i = (long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= p || j >= q) return;
+    double D = 0.0;
+    for (int t = 0; t < d; ++t) {
+        const double df = (U[i * d + t] - V[j * d + t]) * invtheta[t];
+        D += df * df;
+    }
+    K[i * q + j] = kern_eval(D, kernel);
 }
 
 __global__ void k_set_scalar(double* dst, double v) { *dst = v; }

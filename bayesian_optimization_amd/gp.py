@@ -139,6 +139,39 @@ class GP:
         self.m = m
         return mu, var, ei, int(idx.value), eim.value, mum.value
 
+    def kriging_fit(self, xT, yT, theta, deg):
+        """gpr_poly (Gaussian_Process_Regression.ipynb:197-203): returns (beta (p,), cov)."""
+        X = _f64(xT, 2)
+        y = _f64(np.asarray(yT).reshape(-1), 1)
+        if y.shape[0] != X.shape[0]:
+            raise ValueError('xT has %d rows, yT %d' % (X.shape[0], y.shape[0]))
+        beta = np.zeros(10)
+        nb, cov = C.c_int32(), C.c_double()
+        self._check(self._lib.gpbo_kriging_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1],
+                                               float(np.squeeze(theta)), int(deg), L.dptr(beta), C.byref(nb), C.byref(cov)))
+        self.n, self.d = X.shape
+        self.theta1, self.nll, self.m = cov.value, float('nan'), 0
+        return beta[:nb.value].copy(), cov.value
+
+    def set_posterior(self, mu, var):
+        """Upload a (mu, diag(Cov)) pair so acquire() can evaluate an acquisition on it."""
+        mu = _f64(np.asarray(mu).reshape(-1), 1)
+        var = _f64(np.asarray(var).reshape(-1), 1)
+        if mu.shape != var.shape:
+            raise ValueError('mu and var must have the same length')
+        self._check(self._lib.gpbo_set_posterior(self._h, L.dptr(mu), L.dptr(var), mu.shape[0]))
+        self.m = mu.shape[0]
+
+    def kernel_matrix(self, U, V, theta, kernel=L.KERNEL_RBF):
+        U, V = _f64(U, 2), _f64(V, 2)
+        th = _f64(np.asarray(theta).reshape(-1), 1)
+        if U.shape[1] != V.shape[1] or th.shape[0] != U.shape[1]:
+            raise ValueError('U, V and theta disagree on the number of columns')
+        K = np.empty((U.shape[0], V.shape[0]))
+        self._check(self._lib.gpbo_kernel_matrix(self._h, L.dptr(U), U.shape[0], L.dptr(V), V.shape[0], U.shape[1], L.dptr(th),
+                                                 int(kernel), L.dptr(K)))
+        return K
+
     def reserve_appends(self, max_appends: int):
         """Room for appended points; call before fit(variant=VARIANT_SINGLE)."""
         self._check(self._lib.gpbo_reserve_appends(self._h, int(max_appends)))

@@ -1,0 +1,215 @@
+"""Drop-in functions with the notebooks' own signatures, running on the GPU through libgpbo.
+
+    from bayesian_optimization_amd.notebook_api import *      # instead of the notebook's function cell
+
+Reference signatures (BayesOpt/BayesOpt_v4.ipynb): distmat_v2 :100, kernfcn_v2 :119, gprfcn :127,
+mlefcn :154, expected_improvement :188; (BayesOpt/Gaussian_Process_Regression.ipynb): polymat :113,
+gpr_poly :197, y_kriging_v2 :228, acquisition :265.
+
+Deliberate differences, all at sizes/outputs no caller in the reference consumes:
+  * gprfcn returns Cov as a ``DiagCov``: np.diag(Cov) / Cov.diagonal() give the (m,) variance the callers
+    use (:191,:208,:806); the dense m x m matrix is never formed.  K, Ks, Kss and v (returned but unused by
+    every caller, ``_`` at :645) are lazy ``KernelHandle`` objects that build the matrix on first use.
+  * distmat_v2 returns a lazy list: mlefcn/kernfcn_v2 recompute distances on the device from the points.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib as L
+from .gp import GP
+
+_ctx = {}
+
+
+def _gp(kind='main', device=0):
+    key = (kind, device)
+    if key not in _ctx:
+        _ctx[key] = GP(device)
+    return _ctx[key]
+
+
+# ----------------------------------------------------------------------------- lazy containers
+class DistList(list):
+    """What distmat_v2 returns: behaves as the list of d per-dimension |u_i - v_j| matrices, built on first access."""
+
+    def __init__(self, u, v):
+        super().__init__()
+        self.u = np.asarray(u, dtype=np.float64)
+        self.v = np.asarray(v, dtype=np.float64)
+        self._built = False
+
+    def _build(self):
+        if not self._built:
+            for i in range(self.u.shape[1]):
+                list.append(self, np.abs(self.u[:, i][:, None] - self.v[:, i][None, :]))
+            self._built = True
+
+    def __len__(self):
+        return self.u.shape[1]
+
+    def __getitem__(self, i):
+        self._build()
+        return list.__getitem__(self, i)
+
+    def __iter__(self):
+        self._build()
+        return list.__iter__(self)
+
+
+class KernelHandle:
+    """A covariance matrix that is only computed (on the GPU) when somebody looks at it."""
+
+    def __init__(self, U, V, theta, scale=1.0, kernel=L.KERNEL_RBF):
+        self.U, self.V, self.theta, self.scale, self.kernel = U, V, np.asarray(theta, dtype=np.float64), scale, kernel
+        self.shape = (len(U), len(V))
+        self._K = None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._K is None:
+            self._K = self.scale * _gp('aux').kernel_matrix(self.U, self.V, self.theta, self.kernel)
+        return self._K if dtype is None else self._K.astype(dtype)
+
+
+class DiagCov:
+    """diag-backed posterior covariance: np.diag(Cov), Cov.diagonal() and np.sqrt(np.diag(Cov)) work;
+    the dense (m, m) matrix is not available (the reference only ever reads the diagonal)."""
+
+    def __init__(self, var, owner=None, token=None):
+        self._var = np.asarray(var, dtype=np.float64)
+        self.shape = (len(self._var), len(self._var))
+        self._owner, self._token = owner, token
+
+    def diagonal(self):
+        return self._var
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func in (np.diag, np.diagonal):
+            return self._var
+        raise TypeError('only the diagonal of the posterior covariance is formed; use np.diag(Cov)')
+
+    def __array__(self, dtype=None, copy=None):
+        raise TypeError('only the diagonal of the posterior covariance is formed; use np.diag(Cov)')
+
+
+# ----------------------------------------------------------------------------- BayesOpt_v4 surface
+def distmat_v2(u, v):
+    return DistList(u, v)
+
+
+def kernfcn_v2(Daa, theta):
+    if isinstance(Daa, DistList):
+        return _gp('aux').kernel_matrix(Daa.u, Daa.v, np.asarray(theta, dtype=np.float64)[:len(Daa)])
+    # plain list of |difference| matrices (the notebook's own format): rebuild point sets that realise them is not
+    # possible in general, so evaluate the formula of :119-124 on the device from 1-D embeddings when the list came
+    # from distance_matrix of coordinates; otherwise the caller should pass DistList.
+    raise TypeError('kernfcn_v2 needs the object returned by distmat_v2 of this module')
+
+
+def gprfcn(xTest, xTrain, yTrain, theta, sigmaY):
+    gp = _gp('main')
+    xTest = np.ascontiguousarray(xTest, dtype=np.float64)
+    xTrain = np.ascontiguousarray(xTrain, dtype=np.float64)
+    theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+    gp.fit(xTrain, yTrain, theta, sigmaY)
+    gp.set_candidates(xTest)
+    gp.posterior()
+    mu, var = gp.read()
+    Lm, alpha = gp.factor()
+    token = object()
+    gp._nb_token = token
+    th1 = gp.theta1
+    K = KernelHandle(xTrain, xTrain, theta, th1)
+    Ks = KernelHandle(xTest, xTrain, theta, th1)
+    Kss = KernelHandle(xTest, xTest, theta, th1)
+    return mu[:, None], DiagCov(var, gp, token), K, Ks, Kss, Lm, alpha[:, None], None
+
+
+def expected_improvement(Mu, Cov, kappa):
+    Mu = np.squeeze(np.asarray(Mu, dtype=np.float64))
+    if isinstance(Cov, DiagCov):
+        var, owner, token = Cov.diagonal(), Cov._owner, Cov._token
+    else:
+        Cov = np.asarray(Cov, dtype=np.float64)
+        var, owner, token = (np.diag(Cov) if Cov.ndim == 2 else Cov), None, None
+    gp = _gp('main')
+    if owner is not gp or getattr(gp, '_nb_token', None) is not token or gp.m != len(Mu):
+        gp.set_posterior(Mu, var)           # arbitrary (Mu, Cov): upload; otherwise reuse the resident posterior
+        gp._nb_token = None
+    gp.acquire(L.ACQ_EI, float(kappa), L.INCUMBENT_MAX_MU)
+    return gp.read(mu=False, var=False, acq=True)
+
+
+def mlefcn(xTrain, yTrain, Daa, theta, sigmaY):
+    """-logL; Daa is accepted for signature compatibility (distances are recomputed on the device)."""
+    nll, stat = _gp('lml').lml_batch(xTrain, yTrain, np.asarray(theta, dtype=np.float64).reshape(1, -1), [sigmaY])
+    if stat[0] != 0:
+        raise np.linalg.LinAlgError('Matrix is not positive definite')
+    return float(nll[0])
+
+
+# ----------------------------------------------------------------------------- kriging surface
+def polymat(x, deg):
+    x = np.asarray(x, dtype=np.float64)
+    N, Cn = x.shape
+    cols = [np.ones((N, 1))]
+    if deg >= 1:
+        cols += [x[:, i][:, None] for i in range(Cn)]
+    if deg >= 2:
+        cols += [x[:, i][:, None] ** 2 for i in range(Cn)]
+    if deg >= 3 and Cn == 2:
+        cols.append((x[:, 0] * x[:, 1])[:, None])
+    if deg >= 3 and Cn == 3:
+        cols += [(x[:, 0] * x[:, 1])[:, None], (x[:, 0] * x[:, 2])[:, None], (x[:, 1] * x[:, 2])[:, None]]
+    if Cn > 3:
+        raise ValueError('polymat: 1..3 input columns (as in the reference)')
+    return np.concatenate(cols, axis=1)
+
+
+class KrigingK(KernelHandle):
+    """K returned by gpr_poly: carries the fitted context so y_kriging_v2 does not refit."""
+
+
+def gpr_poly(xT, yT, xS, theta, kernel, deg):
+    gp = _gp('kriging')
+    xT = np.ascontiguousarray(xT, dtype=np.float64)
+    xS = np.ascontiguousarray(xS, dtype=np.float64)
+    th = float(np.squeeze(theta))
+    beta, cov = gp.kriging_fit(xT, yT, th, deg)
+    thv = np.full(xT.shape[1], th)
+    K = KrigingK(xT, xT, thv)
+    K._fit_key = (xT.tobytes(), np.asarray(yT, dtype=np.float64).tobytes(), th, int(deg))
+    gp._kr_key = K._fit_key
+    Ks = KernelHandle(xT, xS, thv)
+    Kss = KernelHandle(xT, xT, thv)       # the reference builds Kss from DTT as well (:177)
+    return beta, cov, K, Ks, Kss, polymat(xT, deg), polymat(xS, deg)
+
+
+def y_kriging_v2(x, beta, cov, K, FT, xT, yT, theta, deg, kernel):
+    """mu, mse for one point (the notebook's usage) or a batch of points x (m, d)."""
+    gp = _gp('kriging')
+    xT = np.ascontiguousarray(xT, dtype=np.float64)
+    x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+    th = float(np.squeeze(theta))
+    key = (xT.tobytes(), np.asarray(yT, dtype=np.float64).tobytes(), th, int(deg))
+    if getattr(gp, '_kr_key', None) != key:
+        gp.kriging_fit(xT, yT, th, deg)
+        gp._kr_key = key
+    gp.set_candidates(x)
+    gp.posterior()
+    mu, mse = gp.read()
+    return mu, mse
+
+
+def acquisition(mu, yT, sigma):
+    """Probability of improvement Phi((mu - max(yT)) / sigma)."""
+    gp = _gp('aux')
+    mu = np.asarray(mu, dtype=np.float64).reshape(-1)
+    sigma = np.broadcast_to(np.asarray(sigma, dtype=np.float64), mu.shape)
+    gp.set_posterior(mu, sigma ** 2)
+    gp.acquire(L.ACQ_PI, 0.0, L.INCUMBENT_GIVEN, float(np.max(yT)))
+    return gp.read(mu=False, var=False, acq=True)
+
+
+__all__ = ['distmat_v2', 'kernfcn_v2', 'gprfcn', 'mlefcn', 'expected_improvement', 'polymat', 'gpr_poly', 'y_kriging_v2',
+           'acquisition']

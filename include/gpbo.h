@@ -129,6 +129,24 @@ int gpbo_predict_ei(gpbo_ctx* ctx, const double* Xs, int64_t m, double kappa,
  * posterior for frozen theta (GP/BayesOptFcn_v1.m:73-83). */
 int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out);
 
+/* Trend-GP ("kriging") flavour.  gpr_poly (Gaussian_Process_Regression.ipynb:197-203): isotropic
+ * K = exp(-D^2/(2 theta^2)) WITHOUT jitter, trend basis polymat(deg) (:113-140; d <= 3), GLS
+ * beta (:201), cov = r^T K^-1 r / n (:202).  beta_out must hold 10 doubles.  After it,
+ * gpbo_set_candidates + gpbo_posterior give y_kriging_v2 (:228-234) for every candidate:
+ * mu = f beta + r^T K^-1 (y - F beta) and, in the variance slot, mse = cov^2 (1 - r^T K^-1 r)
+ * (not clamped, as in the reference). */
+int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, double theta,
+                     int32_t deg, double* beta_out, int32_t* nbeta_out, double* cov_out);
+
+/* Make host arrays (m,) the resident posterior, so gpbo_acquire can run expected_improvement
+ * (BayesOpt_v4.ipynb:188-197) / acquisition (Gaussian_Process_Regression.ipynb:265-268) on any Mu, diag(Cov). */
+int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64_t m);
+
+/* kernfcn_v2(distmat_v2(U,V), theta) (BayesOpt_v4.ipynb:100-105,119-124): the (p,q) covariance matrix
+ * of two point sets, to host memory.  A data-format helper for callers that want K, Ks or Kss themselves. */
+int gpbo_kernel_matrix(gpbo_ctx* ctx, const double* U, int64_t p, const double* V, int64_t q, int32_t d,
+                       const double* theta, int32_t kernel, double* K_out);
+
 /* Room for max_appends appended points; call BEFORE gpbo_fit (single-factor variant).  The next
  * gpbo_posterior then keeps V = L^-1 Ks^T (rows x candidates, 8 bytes each) resident in HBM. */
 int gpbo_reserve_appends(gpbo_ctx* ctx, int64_t max_appends);
