@@ -4,12 +4,20 @@
 // 4x4 MFMA tiles (64 accumulator doubles per lane).
 //
 // Operands are staged global -> registers -> LDS, 16 k-values per step, double
-// buffered with one barrier per step.  Both operands sit in LDS k-major
-// ([k][x], x contiguous, row pitch 144 doubles = 1152 B == 128 mod 256) so the
-// MFMA fragment reads (lane l: k = l>>4, x = l&15) are conflict-free ds_read_b64.
+// buffered with one barrier per step; the LDS stores of the next tile are issued
+// in the middle of the MFMA phase so only the barrier itself sits between steps.
 //
 // Layout flags: KCONTIG=true  -> element (x,k) at base[x*ld + k]  (row-major, k contiguous)
 //               KCONTIG=false -> element (x,k) at base[k*ld + x]  (x contiguous)
+// LDS image per operand (18,432 B either way):
+//   KCONTIG=true : row-major [128 x][18]: 8 lanes fetch one row's 128 contiguous bytes and
+//                  store them with ds_write_b128; the MFMA fragment read (lane l: x = l&15,
+//                  k = l>>4) walks rows at pitch 18 doubles = 36 banks: the 16 rows of a lane
+//                  group fall on 16 distinct even banks and the k+1 group on the odd ones.
+//   KCONTIG=false: k-major [16 k][144]: one wave-load is one 1 KiB k-row; fragment reads take
+//                  16 consecutive doubles per lane group, row pitch 1152 B == 128 mod 256.
+// Both fragment reads are conflict-free ds_read_b64.  (A lane map that gathers 16 rows per
+// wave-load costs ~13 % of the MFMA rate: the vector memory pipe, not latency, is the limit.)
 // All tile origins, leading dimensions and k ranges must be multiples of 16 doubles
 // (callers pad every matrix to a multiple of 128).
 #pragma once
@@ -23,10 +31,12 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int TM = 128;
 constexpr int TN = 128;
 constexpr int TK = 16;
-constexpr int LDS_LD = 144;
-constexpr int TILE_DOUBLES = TK * LDS_LD;
+constexpr int LDS_LD = 144;   // k-major image: doubles per k-row
+constexpr int LDS_RK = 18;    // row-major image: doubles per x-row
+constexpr int TILE_DOUBLES = TK * LDS_LD;            // == 128 * LDS_RK
 constexpr int GEMM_LDS_DOUBLES = 4 * TILE_DOUBLES;   // 2 buffers x 2 operands = 73,728 B
 constexpr int GEMM_THREADS = 256;
+static_assert(TK * LDS_LD == 128 * LDS_RK, "both LDS images have the same size");
 
 struct Stage {
     f64x2 v[4];
@@ -38,14 +48,10 @@ __device__ __forceinline__ void load_tile(Stage& s, const double* __restrict__ b
     for (int p = 0; p < 4; ++p) {
         const int q = tid + 256 * p;
         if (KCONTIG) {
-            // one wave-load covers 16 rows x 64 contiguous bytes
-            const int l = q & 63, wb = q >> 6;
-            const int x = (l & 15) + 16 * (wb & 7);
-            const int kp = (l >> 4) + 4 * (wb >> 3);
+            const int x = q >> 3, kp = q & 7;        // 8 lanes = one row's 16 k = 128 contiguous bytes
             s.v[p] = *reinterpret_cast<const f64x2*>(base + (long)x * ld + k0 + 2 * kp);
         } else {
-            // one wave-load covers 1 KiB contiguous (one k-row of the tile)
-            const int k = q >> 6, c2 = q & 63;
+            const int k = q >> 6, c2 = q & 63;       // one wave-load = one 1 KiB k-row
             s.v[p] = *reinterpret_cast<const f64x2*>(base + (long)(k0 + k) * ld + 2 * c2);
         }
     }
@@ -57,17 +63,25 @@ __device__ __forceinline__ void store_tile(const Stage& s, double* lds, int tid)
     for (int p = 0; p < 4; ++p) {
         const int q = tid + 256 * p;
         if (KCONTIG) {
-            const int l = q & 63, wb = q >> 6;
-            const int x = (l & 15) + 16 * (wb & 7);
-            const int kp = (l >> 4) + 4 * (wb >> 3);
-            lds[(2 * kp) * LDS_LD + x] = s.v[p].x;
-            lds[(2 * kp + 1) * LDS_LD + x] = s.v[p].y;
+            const int x = q >> 3, kp = q & 7;
+            *reinterpret_cast<f64x2*>(lds + x * LDS_RK + 2 * kp) = s.v[p];
         } else {
             const int k = q >> 6, c2 = q & 63;
             *reinterpret_cast<f64x2*>(lds + k * LDS_LD + 2 * c2) = s.v[p];
         }
     }
 }
+
+// Offset of this lane's fragment element for 16-row block t = 0 and k-substep 0, and the
+// strides to the next 16-row block / next k-substep (4 k).
+template <bool KCONTIG>
+__device__ __forceinline__ int frag_base(int lane, int x0) {
+    return KCONTIG ? (x0 + (lane & 15)) * LDS_RK + (lane >> 4) : x0 + (lane & 15) + (lane >> 4) * LDS_LD;
+}
+template <bool KCONTIG>
+__device__ __forceinline__ constexpr int frag_tstride() { return KCONTIG ? 16 * LDS_RK : 16; }
+template <bool KCONTIG>
+__device__ __forceinline__ constexpr int frag_kstride() { return KCONTIG ? 4 : 4 * LDS_LD; }
 
 // acc must be zero-initialised (or hold the value to accumulate onto) by the caller.
 template <bool A_KCONTIG, bool B_KCONTIG>
@@ -85,33 +99,34 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
     store_tile<B_KCONTIG>(sb, lds + TILE_DOUBLES, tid);
     __syncthreads();
     int buf = 0;
-    const int frag_off = (lane & 15) + (lane >> 4) * LDS_LD;
+    const int a_off = frag_base<A_KCONTIG>(lane, wr * 64);
+    const int b_off = TILE_DOUBLES + frag_base<B_KCONTIG>(lane, wc * 64);
     for (int k0 = k_begin; k0 < k_end; k0 += TK) {
         const bool has_next = (k0 + TK) < k_end;
         if (has_next) {
             load_tile<A_KCONTIG>(sa, A, lda, k0 + TK, tid);
             load_tile<B_KCONTIG>(sb, B, ldb, k0 + TK, tid);
         }
-        const double* a_l = lds + buf * 2 * TILE_DOUBLES + wr * 64 + frag_off;
-        const double* b_l = lds + buf * 2 * TILE_DOUBLES + TILE_DOUBLES + wc * 64 + frag_off;
+        const double* a_l = lds + buf * 2 * TILE_DOUBLES + a_off;
+        const double* b_l = lds + buf * 2 * TILE_DOUBLES + b_off;
+        double* nxt = lds + (buf ^ 1) * 2 * TILE_DOUBLES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double af[4], bf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                af[t] = a_l[kk * 4 * LDS_LD + t * 16];
-                bf[t] = b_l[kk * 4 * LDS_LD + t * 16];
+                af[t] = a_l[kk * frag_kstride<A_KCONTIG>() + t * frag_tstride<A_KCONTIG>()];
+                bf[t] = b_l[kk * frag_kstride<B_KCONTIG>() + t * frag_tstride<B_KCONTIG>()];
             }
 #pragma unroll
             for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
-        }
-        if (has_next) {
-            double* nxt = lds + (buf ^ 1) * 2 * TILE_DOUBLES;
-            store_tile<A_KCONTIG>(sa, nxt, tid);
-            store_tile<B_KCONTIG>(sb, nxt + TILE_DOUBLES, tid);
+            if (kk == 2 && has_next) {   // the global data has had three k-substeps to arrive
+                store_tile<A_KCONTIG>(sa, nxt, tid);
+                store_tile<B_KCONTIG>(sb, nxt + TILE_DOUBLES, tid);
+            }
         }
         __syncthreads();
         buf ^= 1;

@@ -390,18 +390,22 @@ __global__ __launch_bounds__(256) void k_ks_build(const double* __restrict__ Xs,
 }
 
 // V = W * Bmat (W lower triangular), fused epilogue: per-column sum of squares of the
-// 128 rows of the tile -> partial[ib][j].  Tiles are issued heaviest (largest ib) first.
+// 128 rows of the tile -> partial[ib][j].
 // STORE_V: also keep V rows < v_rows of the tile in the resident buffer Vres[row][j0 + col]
 // (row pitch ldv = number of candidates) for the incremental append path.
+//
+// Tile order: row blocks heaviest first (longest k range), all column blocks of a row block next to
+// each other, so the ~512 resident tiles share one W row panel (served from L2) and the tail of a
+// launch consists of the one-k-block tiles.  An XCD-aware 8x8 super-tile order that also shares the
+// Ks panels measured 9 % slower (tiles marching through k in lockstep expose the miss latency).
 template <bool STORE_V>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __restrict__ W, long ld,
                                                              const double* __restrict__ Bmat, long ldb,
                                                              double* __restrict__ partial, int nb, int nj,
                                                              double* __restrict__ Vres, long ldv, long j0, long m, int v_rows) {
+    const int ib = nb - 1 - blockIdx.x / nj;
+    const int jb = blockIdx.x % nj;
     __shared__ double lds[GEMM_LDS_DOUBLES];
-    const int bid = blockIdx.x;
-    const int ib = nb - 1 - bid / nj;
-    const int jb = bid % nj;
     f64x4 acc[4][4];
     acc_zero(acc);
     gemm_tile_128<true, false>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds);
