@@ -227,17 +227,29 @@ int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, doub
     return GPBO_OK;
 }
 
+// Right-looking blocked Cholesky, panels of 128 columns processed in groups of CHOL_GROUP:
+// inside a group each panel is first brought up to date with the group's earlier panels (a narrow
+// update of one block column), factored (diagonal block in LDS, panel solve by the inverted
+// diagonal block); after the group the whole trailing matrix is updated once with K = 128*group.
+constexpr int CHOL_GROUP = 4;
 int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     Scope s(ctx, T_CHOL);
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
-    for (int p = 0; p < nb; ++p) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, ctx->stream, A, ld, p, ctx->Dinv, info_dev);
-        const int T = nb - p - 1;
-        if (T > 0) {
-            hipLaunchKernelGGL(k_trsm_panel, dim3(T), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, p, ctx->Dinv);
-            hipLaunchKernelGGL(k_syrk_update, dim3(T, T), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, p);
+    for (int p0 = 0; p0 < nb; p0 += CHOL_GROUP) {
+        const int g = std::min(CHOL_GROUP, nb - p0);
+        for (int q = p0; q < p0 + g; ++q) {
+            if (q > p0)   // block column q, rows q..nb-1, against panels p0..q-1
+                hipLaunchKernelGGL(k_syrk_update, dim3(1, nb - q), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, q, q, p0 * PB,
+                                   (q - p0) * PB);
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(POTRF_THREADS), 0, ctx->stream, A, ld, q, ctx->Dinv, info_dev);
+            if (q + 1 < nb)
+                hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, q, ctx->Dinv);
         }
+        const int T = nb - (p0 + g);
+        if (T > 0)
+            hipLaunchKernelGGL(k_syrk_update, dim3(T, T), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB,
+                               g * PB);
     }
     dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4));
     hipLaunchKernelGGL(k_zero_upper, grid, dim3(256), 0, ctx->stream, A, (int)ctx->n_pad);

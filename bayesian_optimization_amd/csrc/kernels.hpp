@@ -11,7 +11,6 @@
 namespace gpbo {
 
 constexpr int PB = 128;    // Cholesky panel / diagonal block
-constexpr int PLD = 130;   // LDS row pitch of the diagonal block (conflict-free pairs)
 
 // params block on the device (doubles)
 enum { P_THETA1 = 0, P_CB = 1, P_C0 = 2, P_C1 = 3, P_NLL = 4, P_YA = 5, P_SUMLOG = 6, P_YMAX = 7, P_INVTHETA = 8,
@@ -55,33 +54,41 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
 
 // ---------------------------------------------------------------------------------------
 // Diagonal block p: in-LDS left-looking Cholesky of the 128x128 block, then its inverse.
-// 256 threads = 128 rows x 2 (the pair splits every dot product by parity of k).
+// 1024 threads = 128 rows x 8 lanes; the 8 lanes of a row split every dot product (k == h mod 8)
+// and combine with three shuffles, so a column step is <= 16 multiply-adds per lane + one barrier.
+// Row pitch 136 doubles: the 4 rows of a 32-lane group start 16 banks apart, 8 lanes x 2 banks each.
 // Writes L (lower, zeros above) back into A and inv(L) (lower, zeros above) into Dinv.
 // info: first failing 1-based global row (pivot <= 0 or NaN), set once.
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
-                                                    int* __restrict__ info) {
+constexpr int POTRF_THREADS = 1024;
+constexpr int PLD = 136;
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
+                                                              int* __restrict__ info) {
     __shared__ double S[PB * PLD];
     __shared__ double dg[PB];
     const int tid = threadIdx.x;
     double* blk = A + (long)p * PB * ld + (long)p * PB;
-    for (int idx = tid; idx < PB * PB; idx += 256) {
+    for (int idx = tid; idx < PB * PB; idx += POTRF_THREADS) {
         const int r = idx >> 7, c = idx & 127;
         S[r * PLD + c] = blk[(long)r * ld + c];
     }
     __syncthreads();
-    const int i = tid >> 1, h = tid & 1;
+    const int i = tid >> 3, h = tid & 7;
     int fail = -1;
     const double* ri = S + i * PLD;
     for (int j = 0; j < PB; ++j) {
         const double* rj = S + j * PLD;
         double s = 0.0, s2 = 0.0;
-        for (int k = h; k < j; k += 2) {
+        for (int k = h; k < j; k += 8) {
             const double ljk = rj[k];
             s += ri[k] * ljk;
             s2 += ljk * ljk;
         }
         s += __shfl_xor(s, 1);
         s2 += __shfl_xor(s2, 1);
+        s += __shfl_xor(s, 2);
+        s2 += __shfl_xor(s2, 2);
+        s += __shfl_xor(s, 4);
+        s2 += __shfl_xor(s2, 4);
         const double piv = rj[j] - s2;
         if (!(piv > 0.0) && fail < 0) fail = j;
         const double dj = sqrt(piv);
@@ -95,7 +102,8 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, long
     if (tid == 0 && fail >= 0) atomicCAS(info, 0, p * PB + fail + 1);
     if (tid < PB) S[tid * PLD + tid] = 1.0 / dg[tid];
     __syncthreads();
-    // inverse: pair (c,h) builds column c of inv(L) in the upper triangle, S[c][i] = inv(L)[i][c]
+    // inverse: the 8 lanes of "row" c build column c of inv(L) in the upper triangle, S[c][r] = inv(L)[r][c].
+    // Column c only reads its own row of the upper triangle and rows of L, so waves never wait for each other.
     {
         const int c = i;
         const double* rc = S + c * PLD;
@@ -103,16 +111,18 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ A, long
             double s = 0.0;
             if (r > c) {
                 const double* rr = S + r * PLD;
-                for (int k = c + h; k < r; k += 2) s += rr[k] * rc[k];
+                for (int k = c + h; k < r; k += 8) s += rr[k] * rc[k];
             }
             s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
             if (r > c && h == 0) S[c * PLD + r] = -s / dg[r];
             __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
     double* dinv = Dinv + (long)p * PB * PB;
-    for (int idx = tid; idx < PB * PB; idx += 256) {
+    for (int idx = tid; idx < PB * PB; idx += POTRF_THREADS) {
         const int r = idx >> 7, c = idx & 127;
         double lv, iv;
         if (c < r) {
@@ -148,17 +158,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_panel(double* __restri
             for (int r = 0; r < 4; ++r) Ap[(long)acc_row(ta, r) * ld + acc_col(tb)] = acc[ta][tb][r];
 }
 
-// Trailing update: A[ib, jb] -= P[ib] * P[jb]^T for p < jb <= ib, P = solved panel p.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restrict__ A, long ld, int p) {
-    const int ib = p + 1 + blockIdx.y;
-    const int jb = p + 1 + blockIdx.x;
+// Trailing update with a group of solved panels: A[ib, jb] -= P[ib] * P[jb]^T for jb0 <= jb <= ib,
+// P[x] = A[x, kcol0 : kcol0 + klen] (klen = 128 .. 512: several adjacent panels at once, so the
+// read-modify-write of a tile of A is paid once per group instead of once per panel).
+// grid = (number of jb, number of ib); ib = ib0 + blockIdx.y, jb = jb0 + blockIdx.x.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restrict__ A, long ld, int ib0, int jb0, int kcol0,
+                                                              int klen) {
+    const int ib = ib0 + blockIdx.y;
+    const int jb = jb0 + blockIdx.x;
     if (jb > ib) return;
     __shared__ double lds[GEMM_LDS_DOUBLES];
-    const double* Pi = A + (long)ib * PB * ld + (long)p * PB;
-    const double* Pj = A + (long)jb * PB * ld + (long)p * PB;
+    const double* Pi = A + (long)ib * PB * ld + kcol0;
+    const double* Pj = A + (long)jb * PB * ld + kcol0;
     f64x4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128<true, true>(Pi, ld, Pj, ld, 0, PB, acc, lds);
+    gemm_tile_128<true, true>(Pi, ld, Pj, ld, 0, klen, acc, lds);
     double* C = A + (long)ib * PB * ld + (long)jb * PB;
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)

