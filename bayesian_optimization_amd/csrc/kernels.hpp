@@ -53,91 +53,152 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// Diagonal block p: in-LDS left-looking Cholesky of the 128x128 block, then its inverse.
-// 1024 threads = 128 rows x 8 lanes; the 8 lanes of a row split every dot product (k == h mod 8)
-// and combine with three shuffles, so a column step is <= 16 multiply-adds per lane + one barrier.
-// Row pitch 136 doubles: the 4 rows of a 32-lane group start 16 banks apart, 8 lanes x 2 banks each.
+
+// Diagonal block p: right-looking Cholesky of the 128x128 block, then its inverse, in one workgroup
+// of 256 threads.  The block is cut into 16x16 register tiles of 8x8; thread (tr, tc) owns tile
+// (tr, tc) (the 136 lower tiles do work).  Column step j: the owners of tile column j/8 publish the
+// raw column through a double-buffered 128-entry LDS vector, one barrier, then every thread scales by
+// 1/sqrt(pivot) and applies the rank-1 update to its 64 registers (static register indices: the
+// loop over the 8 columns of a tile column is unrolled).  The inverse is the same elimination run on
+// X = I: row j of X is published, rows below subtract L[r][j] * X[j][:].  256 barriers in total and
+// no redundant arithmetic, against 128 rows x 8 lanes recomputing every pivot in a reduction form
+// that ran at 3,600 cycles per column.
 // Writes L (lower, zeros above) back into A and inv(L) (lower, zeros above) into Dinv.
 // info: first failing 1-based global row (pivot <= 0 or NaN), set once.
-constexpr int POTRF_THREADS = 1024;
-constexpr int PLD = 136;
+constexpr int POTRF_THREADS = 256;
+constexpr int PLD = 129;   // LDS pitch of the copy of L used by the inverse (column reads, 4 rows per wave)
 __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
                                                               int* __restrict__ info) {
-    __shared__ double S[PB * PLD];
-    __shared__ double dg[PB];
+    __shared__ double S[PB * PLD];      // L, row-major, for the inverse phase
+    __shared__ double vec[2][PB];       // published column (factor) / row (inverse), double buffered
+    __shared__ double dg[PB];           // diagonal of L
     const int tid = threadIdx.x;
+    const int tr = tid >> 4, tc = tid & 15;
+    const bool lower = tr >= tc;
     double* blk = A + (long)p * PB * ld + (long)p * PB;
-    for (int idx = tid; idx < PB * PB; idx += POTRF_THREADS) {
-        const int r = idx >> 7, c = idx & 127;
-        S[r * PLD + c] = blk[(long)r * ld + c];
-    }
-    __syncthreads();
-    const int i = tid >> 3, h = tid & 7;
+    double a[8][8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; cc += 2) {
+            const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)(tr * 8 + rr) * ld + tc * 8 + cc);
+            a[rr][cc] = v.x;
+            a[rr][cc + 1] = v.y;
+        }
     int fail = -1;
-    const double* ri = S + i * PLD;
-    for (int j = 0; j < PB; ++j) {
-        const double* rj = S + j * PLD;
-        double s = 0.0, s2 = 0.0;
-        for (int k = h; k < j; k += 8) {
-            const double ljk = rj[k];
-            s += ri[k] * ljk;
-            s2 += ljk * ljk;
+    for (int jt = 0; jt < 16; ++jt) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = jt * 8 + jj;
+            double* buf = vec[j & 1];
+            if (tc == jt && lower) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) buf[tr * 8 + rr] = a[rr][jj];
+            }
+            __syncthreads();
+            const double piv = buf[j];
+            if (!(piv > 0.0) && fail < 0) fail = j;
+            const double d = sqrt(piv);
+            const double rsq = 1.0 / d;
+            if (tc >= jt && lower) {
+                double lr[8], lc[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    lr[t] = buf[tr * 8 + t] * rsq;
+                    lc[t] = buf[tc * 8 + t] * rsq;
+                }
+                if (tc == jt) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) a[rr][jj] = lr[rr];          // final column j of L (rows > j)
+                    if (tr == jt) a[jj][jj] = d;
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+                        for (int cc = jj + 1; cc < 8; ++cc) a[rr][cc] = fma(-lr[rr], lc[cc], a[rr][cc]);
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = fma(-lr[rr], lc[cc], a[rr][cc]);
+                }
+            }
+            if (tid == 0) dg[j] = d;
         }
-        s += __shfl_xor(s, 1);
-        s2 += __shfl_xor(s2, 1);
-        s += __shfl_xor(s, 2);
-        s2 += __shfl_xor(s2, 2);
-        s += __shfl_xor(s, 4);
-        s2 += __shfl_xor(s2, 4);
-        const double piv = rj[j] - s2;
-        if (!(piv > 0.0) && fail < 0) fail = j;
-        const double dj = sqrt(piv);
-        const double v = (ri[j] - s) / dj;
-        if (h == 0) {
-            if (i > j) S[i * PLD + j] = v;
-            if (i == j) dg[j] = dj;
-        }
-        __syncthreads();
     }
     if (tid == 0 && fail >= 0) atomicCAS(info, 0, p * PB + fail + 1);
-    if (tid < PB) S[tid * PLD + tid] = 1.0 / dg[tid];
+    // L -> global (zeros above the diagonal) and -> LDS for the inverse
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int r = tr * 8 + rr, c = tc * 8 + cc;
+            const double v = (c <= r) ? a[rr][cc] : 0.0;
+            S[r * PLD + c] = v;
+            a[rr][cc] = (r == c) ? 1.0 : 0.0;                                   // X = I
+        }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; cc += 2) {
+            const int r = tr * 8 + rr, c = tc * 8 + cc;
+            f64x2 v;
+            v.x = S[r * PLD + c];      // own values, written by this thread just above
+            v.y = S[r * PLD + c + 1];
+            *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
+        }
     __syncthreads();
-    // inverse: the 8 lanes of "row" c build column c of inv(L) in the upper triangle, S[c][r] = inv(L)[r][c].
-    // Column c only reads its own row of the upper triangle and rows of L, so waves never wait for each other.
-    {
-        const int c = i;
-        const double* rc = S + c * PLD;
-        for (int r = 1; r < PB; ++r) {
-            double s = 0.0;
-            if (r > c) {
-                const double* rr = S + r * PLD;
-                for (int k = c + h; k < r; k += 8) s += rr[k] * rc[k];
+    // inverse: forward elimination on X = I.  Step j: row j of X (scaled by 1/d_j) is final and published;
+    // rows r > j subtract L[r][j] * X[j][:].
+    for (int jt = 0; jt < 16; ++jt) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = jt * 8 + jj;
+            double* buf = vec[j & 1];
+            if (tr == jt && lower) {
+                const double rd = 1.0 / dg[j];
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    a[jj][cc] *= rd;
+                    buf[tc * 8 + cc] = a[jj][cc];
+                }
             }
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            if (r > c && h == 0) S[c * PLD + r] = -s / dg[r];
-            __builtin_amdgcn_wave_barrier();
+            if (tr == jt && !lower) {          // columns right of the diagonal tile: X[j][c] = 0
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) buf[tc * 8 + cc] = 0.0;
+            }
+            __syncthreads();
+            if (tr >= jt && lower) {
+                double xr[8], lcol[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    xr[t] = buf[tc * 8 + t];
+                    lcol[t] = S[(tr * 8 + t) * PLD + j];
+                }
+                if (tr == jt) {
+#pragma unroll
+                    for (int rr = jj + 1; rr < 8; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = fma(-lcol[rr], xr[cc], a[rr][cc]);
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = fma(-lcol[rr], xr[cc], a[rr][cc]);
+                }
+            }
         }
     }
-    __syncthreads();
     double* dinv = Dinv + (long)p * PB * PB;
-    for (int idx = tid; idx < PB * PB; idx += POTRF_THREADS) {
-        const int r = idx >> 7, c = idx & 127;
-        double lv, iv;
-        if (c < r) {
-            lv = S[r * PLD + c];
-            iv = S[c * PLD + r];
-        } else if (c == r) {
-            lv = dg[r];
-            iv = S[r * PLD + r];
-        } else {
-            lv = 0.0;
-            iv = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; cc += 2) {
+            const int r = tr * 8 + rr, c = tc * 8 + cc;
+            f64x2 v;
+            v.x = (c <= r) ? a[rr][cc] : 0.0;
+            v.y = (c + 1 <= r) ? a[rr][cc + 1] : 0.0;
+            *reinterpret_cast<f64x2*>(dinv + r * PB + c) = v;
         }
-        blk[(long)r * ld + c] = lv;
-        dinv[idx] = iv;
-    }
 }
 
 // Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T

@@ -1,0 +1,35 @@
+// Debug probe: in-kernel cycle stamps of k_potrf_diag (load / factor / inverse+store) and the clock it runs at.
+#include "../bayesian_optimization_amd/csrc/kernels.hpp"
+#include <cstdio>
+#include <vector>
+using namespace gpbo;
+int main() {
+    const int n = 128;
+    std::vector<double> A(n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) A[i * n + j] = exp(-0.5 * (i - j) * (i - j) / 400.0) + (i == j ? 0.01 : 0.0);
+    double *dA, *dinv; int* info;
+    (void)hipMalloc(&dA, n * n * 8); (void)hipMalloc(&dinv, n * n * 8); (void)hipMalloc(&info, 64);
+    for (int rep = 0; rep < 5; ++rep) {
+        (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+        (void)hipMemset(info, 0, 64);
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0);
+        k_potrf_diag<<<1, POTRF_THREADS>>>(dA, n, 0, dinv, info);
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        std::vector<double> L(n * n), W(n * n);
+        (void)hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(W.data(), dinv, n * n * 8, hipMemcpyDeviceToHost);
+        double e1m = 0, e2m = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double s1 = 0, s2 = 0;
+                for (int k = 0; k < n; ++k) { s1 += L[i * n + k] * L[j * n + k]; s2 += W[i * n + k] * L[k * n + j]; }
+                e1m = fmax(e1m, fabs(s1 - A[i * n + j])); e2m = fmax(e2m, fabs(s2 - (i == j)));
+            }
+        printf("event %.1f us  |LL^T - A| %.2e  |WL - I| %.2e\n", ms * 1e3, e1m, e2m);
+    }
+    return 0;
+}

@@ -37,7 +37,10 @@ def test_golden_vectors(gp0, name):
     assert relmax(mu, g['Mu']) <= (1e-5 if loose else TOL_MU)
     assert relmax(var, g['var']) <= (1e-5 if loose else TOL_VAR)
     assert relmax(ei, g['ei']) <= (1e-4 if loose else TOL_VAR)
-    assert abs(gp0.nll - float(g['nll'])) <= (1e-6 if loose else 1e-10) * abs(float(g['nll']))
+    # duplicated training rows with sigmaY = 0: the pivots of the duplicates are pure round-off (~1e-14), so
+    # sum(log(diag L)) is not reproducible between two evaluation orders even though mean/variance are
+    nll_tol = 1e-4 if name == 'g5_dup_train_s0' else (1e-6 if loose else 1e-10)
+    assert abs(gp0.nll - float(g['nll'])) <= nll_tol * abs(float(g['nll']))
     assert idx == int(g['argmax'])
     assert idx == int(np.argmax(ei)) and ei_max == ei[idx] and mu_max == np.max(mu)
     if 'L' in g.files and not loose:
