@@ -1074,39 +1074,67 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         if (!(sigmas[b] >= 0)) BADARG("lml_batch: sigmas must be >= 0");
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = round_up(n, PB);
-    CHK(ensure_model(ctx, n_pad, d, true));
-    ctx->fitted = false;             // the model buffers are reused as work space
-    ctx->have_posterior = false;
-    ctx->have_factor = false;
-    ctx->n = n;
-    ctx->n_pad = n_pad;
-    ctx->nb = n_pad / PB;
-    ctx->d = d;
-    ctx->kernel = kernel;
-    ctx->variant = GPBO_VARIANT_SINGLE;
-    const int nb = (int)ctx->nb;
+    const int nb = (int)(n_pad / PB);
     const int ntiles = nb * nb;
 
-    double *Xraw = nullptr, *th_dev = nullptr, *onll = nullptr, *ograd = nullptr, *gpart = nullptr;
+    // The settings are independent.  Each lane = a context of its own (work matrices + stream); settings are dealt
+    // round-robin over the lanes so that the latency-bound parts of one factorisation (diagonal blocks, panel
+    // solves, triangular solves) overlap the MFMA-bound updates of the others.  Lane 0 is the caller's context.
+    int lanes = 4;
+    if (const char* e = getenv("GPBO_LML_STREAMS")) lanes = atoi(e);
+    lanes = std::max(1, std::min(lanes, std::min<int>(B, 8)));
+    std::vector<gpbo_ctx*> lane(lanes, nullptr);
+    lane[0] = ctx;
+    double *Xraw = nullptr, *th_dev = nullptr, *onll = nullptr, *ograd = nullptr;
+    std::vector<double*> gpart(lanes, nullptr);
     int* infos = nullptr;
     auto cleanup = [&]() {
-        for (void* p : {(void*)Xraw, (void*)th_dev, (void*)onll, (void*)ograd, (void*)gpart, (void*)infos})
+        for (int l = 0; l < lanes; ++l) {
+            if (lane[l]) hipStreamSynchronize(lane[l]->stream);
+            if (gpart[l]) hipFree(gpart[l]);
+            if (l > 0 && lane[l]) gpbo_destroy(lane[l]);
+        }
+        for (void* p : {(void*)Xraw, (void*)th_dev, (void*)onll, (void*)ograd, (void*)infos})
             if (p) hipFree(p);
     };
-#define LCHK(expr)                                                    \
-    do {                                                              \
-        hipError_t e_ = (expr);                                       \
-        if (e_ != hipSuccess) {                                       \
+#define LCHK(expr)                                                        \
+    do {                                                                  \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess) {                                           \
             ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_); \
-            cleanup();                                                \
-            return GPBO_ERR_HIP;                                      \
-        }                                                             \
+            cleanup();                                                    \
+            return GPBO_ERR_HIP;                                          \
+        }                                                                 \
     } while (0)
+    for (int l = 0; l < lanes; ++l) {
+        if (l > 0 && gpbo_create(ctx->device, &lane[l]) != GPBO_OK) {
+            ctx->err = "lml_batch: could not create a work context";
+            cleanup();
+            return GPBO_ERR_HIP;
+        }
+        gpbo_ctx* c = lane[l];
+        int st = ensure_model(c, n_pad, d, true);
+        if (st != GPBO_OK) {
+            if (l > 0) ctx->err = c->err;
+            cleanup();
+            return st;
+        }
+        c->fitted = false;             // the model buffers are work space here
+        c->have_posterior = false;
+        c->have_factor = false;
+        c->inc_valid = false;
+        c->n = n;
+        c->n_pad = n_pad;
+        c->nb = nb;
+        c->d = d;
+        c->kernel = kernel;
+        c->variant = GPBO_VARIANT_SINGLE;
+        if (grad_out) LCHK(hipMalloc((void**)&gpart[l], (size_t)ntiles * GRAD_D * 8));
+    }
     LCHK(hipMalloc((void**)&Xraw, (size_t)d * n_pad * 8));
     LCHK(hipMalloc((void**)&th_dev, (size_t)B * d * 8));
     LCHK(hipMalloc((void**)&onll, (size_t)B * 8));
     LCHK(hipMalloc((void**)&ograd, (size_t)B * d * 8));
-    LCHK(hipMalloc((void**)&gpart, (size_t)ntiles * GRAD_D * 8));
     LCHK(hipMalloc((void**)&infos, (size_t)B * sizeof(int)));
     {
         std::vector<double> xr((size_t)d * n_pad, 0.0), yp(n_pad, 0.0);
@@ -1114,58 +1142,59 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             for (int64_t i = 0; i < n; ++i) xr[(size_t)t * n_pad + i] = X[i * d + t];
         for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
         LCHK(hipMemcpy(Xraw, xr.data(), xr.size() * 8, hipMemcpyHostToDevice));
-        LCHK(hipMemcpy(ctx->yv, yp.data(), yp.size() * 8, hipMemcpyHostToDevice));
+        for (int l = 0; l < lanes; ++l) LCHK(hipMemcpy(lane[l]->yv, yp.data(), yp.size() * 8, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(th_dev, thetas, (size_t)B * d * 8, hipMemcpyHostToDevice));
-        LCHK(hipMemsetAsync(infos, 0, (size_t)B * sizeof(int), ctx->stream));
+        LCHK(hipMemset(infos, 0, (size_t)B * sizeof(int)));
+        LCHK(hipDeviceSynchronize());
     }
-    timing_begin(ctx);
-    {
-        Scope tot(ctx, T_TOTAL);
-        for (int b = 0; b < B; ++b) {
-            const double eps = (sigmas[b] == 0) ? 1e-15 * (double)n : sigmas[b] * sigmas[b];
-            hipLaunchKernelGGL(k_setup_setting, dim3((unsigned)((n_pad + 255) / 256), (unsigned)d), dim3(256), 0, ctx->stream,
-                               (const double*)Xraw, (const double*)(th_dev + (size_t)b * d), (int)d, (int)n_pad, ctx->Xts, ctx->params);
-            int st = launch_kernel_matrix(ctx, ctx->bufA, nullptr, eps);
-            if (st == GPBO_OK) st = launch_cholesky(ctx, ctx->bufA, infos + b);
-            if (st == GPBO_OK) st = launch_trsv(ctx, ctx->bufA);
-            if (st != GPBO_OK) {
-                cleanup();
-                return st;
-            }
-            hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bufA, (long)n_pad,
-                               (const double*)ctx->yv, (const double*)ctx->alpha1, ctx->alpha, (int)n, (int)n_pad,
-                               (int)GPBO_VARIANT_SINGLE, ctx->params);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int l = 0; l < lanes; ++l) timing_begin(lane[l]);
+    for (int b = 0; b < B; ++b) {
+        gpbo_ctx* c = lane[b % lanes];
+        const double eps = (sigmas[b] == 0) ? 1e-15 * (double)n : sigmas[b] * sigmas[b];
+        hipLaunchKernelGGL(k_setup_setting, dim3((unsigned)((n_pad + 255) / 256), (unsigned)d), dim3(256), 0, c->stream,
+                           (const double*)Xraw, (const double*)(th_dev + (size_t)b * d), (int)d, (int)n_pad, c->Xts, c->params);
+        int st = launch_kernel_matrix(c, c->bufA, nullptr, eps);
+        if (st == GPBO_OK) st = launch_cholesky(c, c->bufA, infos + b);
+        if (st == GPBO_OK) st = launch_trsv(c, c->bufA);
+        if (st == GPBO_OK) {
+            hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, c->stream, (const double*)c->bufA, (long)n_pad,
+                               (const double*)c->yv, (const double*)c->alpha1, c->alpha, (int)n, (int)n_pad,
+                               (int)GPBO_VARIANT_SINGLE, c->params);
             if (grad_out) {
-                st = launch_inverse(ctx, ctx->bufA, ctx->bufW, ctx->bufB);
-                if (st != GPBO_OK) {
-                    cleanup();
-                    return st;
+                st = launch_inverse(c, c->bufA, c->bufW, c->bufB);
+                if (st == GPBO_OK) {
+                    hipMemsetAsync(gpart[b % lanes], 0, (size_t)ntiles * GRAD_D * 8, c->stream);
+                    hipLaunchKernelGGL(k_lml_grad_tiles, dim3(nb, nb), dim3(GEMM_THREADS), 0, c->stream, (const double*)c->bufW,
+                                       (long)n_pad, (const double*)c->Xts, (int)n, (int)n_pad, (int)d, (const double*)c->alpha1,
+                                       (const double*)c->params, gpart[b % lanes], nb);
                 }
-                hipMemsetAsync(gpart, 0, (size_t)ntiles * GRAD_D * 8, ctx->stream);
-                hipLaunchKernelGGL(k_lml_grad_tiles, dim3(nb, nb), dim3(GEMM_THREADS), 0, ctx->stream, (const double*)ctx->bufW,
-                                   (long)n_pad, (const double*)ctx->Xts, (int)n, (int)n_pad, (int)d, (const double*)ctx->alpha1,
-                                   (const double*)ctx->params, gpart, nb);
             }
-            hipLaunchKernelGGL(k_lml_store, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->params,
-                               (const int*)(infos + b), (const double*)gpart, ntiles, (int)d, grad_out ? 1 : 0, onll + b,
-                               ograd + (size_t)b * d);
+        }
+        if (st != GPBO_OK) {
+            if (c != ctx) ctx->err = c->err;
+            cleanup();
+            return st;
+        }
+        hipLaunchKernelGGL(k_lml_store, dim3(1), dim3(256), 0, c->stream, (const double*)c->params, (const int*)(infos + b),
+                           (const double*)gpart[b % lanes], ntiles, (int)d, grad_out ? 1 : 0, onll + b, ograd + (size_t)b * d);
+        // the event pool of a lane grows with every launch sequence; recycle it when the lane's stream is idle enough
+        if (c->pool_used > 4096) {
+            hipStreamSynchronize(c->stream);
+            timing_begin(c);
         }
     }
     LCHK(hipGetLastError());
+    for (int l = 0; l < lanes; ++l) LCHK(hipStreamSynchronize(lane[l]->stream));
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::vector<int> hinfo(B);
-    LCHK(hipMemcpyAsync(nll_out, onll, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (grad_out) LCHK(hipMemcpyAsync(grad_out, ograd, (size_t)B * d * 8, hipMemcpyDeviceToHost, ctx->stream));
-    LCHK(hipMemcpyAsync(hinfo.data(), infos, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    LCHK(hipStreamSynchronize(ctx->stream));
+    LCHK(hipMemcpy(nll_out, onll, (size_t)B * 8, hipMemcpyDeviceToHost));
+    if (grad_out) LCHK(hipMemcpy(grad_out, ograd, (size_t)B * d * 8, hipMemcpyDeviceToHost));
+    LCHK(hipMemcpy(hinfo.data(), infos, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
 #undef LCHK
-    double ms[T_NCAT], cnt[T_NCAT];
-    timing_collect(ctx, ms, cnt);
-    ctx->tm.fit_total_ms = ms[T_TOTAL];
-    ctx->tm.kbuild_ms = ms[T_KBUILD];
-    ctx->tm.chol_ms = ms[T_CHOL];
+    ctx->tm.fit_total_ms = wall_ms;      // host wall time of the whole sweep (several streams run concurrently)
     ctx->tm.chol_count = B;
-    ctx->tm.trsv_ms = ms[T_TRSV];
-    ctx->tm.inverse_ms = ms[T_INV];
+    ctx->tm.kbuild_ms = ctx->tm.chol_ms = ctx->tm.trsv_ms = ctx->tm.inverse_ms = 0;
     for (int b = 0; b < B; ++b) {
         const bool bad = hinfo[b] != 0 || !std::isfinite(nll_out[b]);
         if (status_out) status_out[b] = bad ? GPBO_ERR_NOT_PD : GPBO_OK;

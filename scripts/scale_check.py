@@ -24,7 +24,7 @@ if 'cfg3' in which:
     a1 = al * gp.theta1
     print('identity mu: max|mu - (y - s2 a1)| / max|y| = %.2e' % (np.max(np.abs(mu - (y[:4096] - cfg['sigmaY'] ** 2 * a1[:4096]))) / np.max(np.abs(y))), 'var range', var.min(), var.max(), 'theta1', gp.theta1, flush=True)
 if 'cfg5' in which:
-    n, d, B = 16384, 8, 4
+    n, d, B = 16384, 8, 16
     X = synth.uniform(5, n * d).reshape(n, d); y = np.sin(3 * X.sum(1)) + 0.1 * synth.normal(105, n)
     thetas = np.outer(np.geomspace(0.25, 2.0, B), np.full(d, 0.5)); sig = np.geomspace(1e-2, 1, B)
     for grad in (False, True):
