@@ -45,6 +45,113 @@ def cpu_baseline(cfg, X, y, theta, Xs_sample):
                 fit_seconds=t_fit), st, (mu, var)
 
 
+def secondary(a):
+    """The two other GPU configurations of BASELINE.json, same launch contract and JSON shape.
+    cfg4: BayesOpt_v4-style loop, theta frozen: EI iterations with incremental append on a 64^4 candidate lattice
+          (a step = one iteration: acquisition + argmax + border-append + the HBM-streaming sweep of the resident V).
+    cfg5: 256 (length-scale, noise) settings of -logL + analytic gradient at n = 16384 (a step = the whole sweep of this
+          rank's share of the settings; ranks take disjoint settings, no exchange)."""
+    import torch
+    import torch.distributed as dist
+    import bayesian_optimization_amd as bo
+    from bayesian_optimization_amd import GP, synth
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def maxtime(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    gp = GP(local_rank)
+    if a.config == 'cfg4':
+        d, side, n0 = 4, 64, 16
+        g1 = (np.arange(side) + 0.5) / side
+        grid = np.stack(np.meshgrid(g1, g1, g1, g1, indexing='ij'), -1).reshape(-1, d)     # lexicographic, as the notebooks' nested loops
+        f = lambda x: np.exp(-8 * np.sum((x - 0.37) ** 2, -1)) + 0.5 * np.exp(-20 * np.sum((x - 0.8) ** 2, -1))
+        X0 = synth.uniform(4 + rank, n0 * d).reshape(n0, d)          # every rank runs its own independent loop (replicas)
+        iters = a.iters
+        gp.reserve_appends(iters + a.warmup)
+        gp.fit(X0, f(X0), np.full(d, 0.25), 1e-2, variant=bo.VARIANT_SINGLE)
+        gp.set_candidates(grid)
+        gp.posterior()
+        m = len(grid)
+        sweep_ms, bytes_alg = 0.0, 0.0
+        for it in range(a.warmup):
+            jj, _ = gp.acquire(bo.ACQ_EI, 0.01)
+            gp.append(grid[jj], float(f(grid[jj])))
+        barrier()
+        t0 = time.perf_counter()
+        for it in range(iters):
+            jj, ei = gp.acquire(bo.ACQ_EI, 0.01)
+            n_before = gp.n
+            gp.append(grid[jj], float(f(grid[jj])))
+            tm = gp.timings()
+            sweep_ms += tm['append_sweep_ms']
+            bytes_alg += m * (8.0 * n_before + 8 + 32 + 8 * d)     # V read + new V row + (mu, var r/w; sum v^2 r/w) + candidates
+        barrier()
+        dt = maxtime(time.perf_counter() - t0)
+        if rank == 0:
+            achieved = bytes_alg / (sweep_ms * 1e-3) / 1e9
+            print(json.dumps({
+                'metric': 'bo_loop_iterations_per_sec', 'value': world * iters / dt, 'unit': 'iterations/s', 'n_gpus': world,
+                'steps': iters, 'warmup': a.warmup, 'ms_per_step': dt / iters * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': 'cfg4: %d EI iterations, incremental append (theta frozen, single-factor posterior), '
+                                       '64^4 = %d candidate lattice, d=4, n0=%d, sigmaY=1e-2; one independent loop per GPU' % (iters, m, n0),
+                           'n_final': gp.n, 'best_y': float(gp.y_max)},
+                'roofline': {'bound': 'hbm', 'kernel': 'k_append_sweep', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                             'frac': achieved / 8000.0, 'traffic': None, 'avg_launch_ms': sweep_ms / iters,
+                             'bytes_per_launch_avg': bytes_alg / iters}}), flush=True)
+    else:
+        n, d = 16384, 8
+        Btot = 256
+        per = a.settings if a.settings else max(1, Btot // world)
+        X = synth.uniform(5, n * d).reshape(n, d)
+        y = np.sin(3 * X.sum(1)) + 0.1 * synth.normal(105, n)
+        mult = np.geomspace(0.25, 2.0, 16)
+        sigs = np.geomspace(1e-2, 1.0, 16)
+        allset = [(mm, ss) for mm in mult for ss in sigs]
+        mine = [allset[(rank * per + i) % Btot] for i in range(per)]
+        thetas = np.array([np.full(d, 0.5 * mm) for mm, _ in mine])
+        sig = np.array([ss for _, ss in mine])
+        for _ in range(a.warmup):
+            gp.lml_batch(X, y, thetas[:2], sig[:2], grad=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            nll, grad, stat = gp.lml_batch(X, y, thetas, sig, grad=True)
+        barrier()
+        dt = maxtime(time.perf_counter() - t0)
+        if rank == 0:
+            flops = float(n) ** 3 * per * a.steps * world       # n^3/3 Cholesky + n^3/3 inverse + n^3/3 W^T W per setting
+            achieved = flops / dt / 1e12 / world
+            print(json.dumps({
+                'metric': 'lml_grad_settings_per_sec', 'value': world * per * a.steps / dt, 'unit': 'settings/s', 'n_gpus': world,
+                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': 'cfg5: -logL + analytic gradient, n=%d, d=%d, RBF, %d settings per GPU (16 length-scale multipliers x 16 sigmaY)' % (n, d, per),
+                           'failed_settings': int(np.sum(stat != 0))},
+                'roofline': {'bound': 'mfma', 'kernel': 'whole sweep (Cholesky + inverse + W^T W tiles)', 'achieved': achieved,
+                             'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None}}),
+                flush=True)
+    gp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -55,7 +162,11 @@ def main():
     ap.add_argument('--n', type=int, default=0, help='training points (default: the config\'s n)')
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--iters', type=int, default=200, help='cfg4: EI iterations')
+    ap.add_argument('--settings', type=int, default=0, help='cfg5: settings per GPU (default 256 / gpus)')
     a = ap.parse_args()
+    if a.config in ('cfg4', 'cfg5'):
+        return secondary(a)
 
     import torch
     import torch.distributed as dist

@@ -299,3 +299,38 @@ def test_incremental_append_equals_refit(gp0):
     with pytest.raises(ValueError):
         gpi.append(X[0], y[0])                 # reserved rows exhausted
     gpi.close()
+
+
+def test_config3_shape_identities(gp0):
+    """n = 32768, d = 8, Matern-5/2 (the 64M-candidate configuration's model).  A CPU oracle at this size takes
+    minutes, so parity rests on identities that hold for any n: at a training input x_i
+        mu_i  = y_i - sigma^2 alpha1_i                        (K (K + s2 I)^-1 y = y - s2 alpha1)
+        var_i = sigma^2 - sigma^4 [(theta1 K + s2 I)^-1]_ii    (v4 two-factor form), [M^-1]_ii = sum_r W[r][i]^2
+    plus bounds, determinism, and a small-n oracle check of the same code path (test_matern_and_single_factor_variants)."""
+    import torch
+    from bayesian_optimization_amd import dist as gdist, synth as sy
+    cfg = sy.CONFIGS['cfg3']
+    X, y, theta = sy.training_set(cfg)
+    s2 = cfg['sigmaY'] ** 2
+    gp0.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
+    _, alpha = gp0.factor(want_L=False)
+    a1 = alpha * gp0.theta1
+    (W, _, _, _), sd = gdist.model_tensors(gp0)
+    minv_diag = (W.reshape(sd.n_pad, sd.n_pad)[:, :sd.n] ** 2).sum(0).cpu().numpy()
+    sel = np.arange(0, cfg['n'], 7)[:4096]
+    gp0.set_candidates(X[sel])
+    gp0.posterior()
+    mu, var = gp0.read()
+    assert np.max(np.abs(mu - (y[sel] - s2 * a1[sel]))) <= 1e-10 * np.max(np.abs(y))
+    assert np.max(np.abs(var - (s2 - s2 * s2 * minv_diag[sel]))) <= 1e-8 * gp0.theta1
+    Xs = sy.candidates(cfg, 0, 8192)
+    gp0.set_candidates(Xs)
+    m1 = gp0.posterior()
+    mu1, var1 = gp0.read()
+    idx, best = gp0.acquire(bo.ACQ_EI, cfg['kappa'])
+    ei = gp0.read(mu=False, var=False, acq=True)
+    assert np.all(var1 >= 0) and np.all(var1 <= gp0.theta1 * (1 + 1e-12)) and m1 == np.max(mu1)
+    assert idx == int(np.argmax(ei)) and np.all(np.isfinite(ei)) and np.all(ei >= 0)
+    gp0.posterior()
+    mu2, var2 = gp0.read()
+    assert np.array_equal(mu1, mu2) and np.array_equal(var1, var2)
