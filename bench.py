@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the GP posterior + EI + argmax sweep (the hot path) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3] [--m M] [--n N_TRAIN]
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3] [--candidates M] [--n-train N]
 
 A step = one full pass over this rank's resident candidate block: K(X*,X) tiles, posterior mean,
 variance (W * Ks^T with fused column sum of squares on fp64 MFMA), max(Mu) [all-reduce], EI, argmax
@@ -45,6 +45,35 @@ def cpu_baseline(cfg, X, y, theta, Xs_sample):
                 fit_seconds=t_fit), st, (mu, var)
 
 
+def _dist_setup():
+    """(world, rank, device index, backend).  GPBO_DIST_BACKEND=gloo and GPBO_FORCE_DEVICE=0 allow a multi-rank
+    rehearsal on a single-GPU box; the default is one rank per GPU over nccl (= RCCL)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = int(os.environ['GPBO_FORCE_DEVICE']) if 'GPBO_FORCE_DEVICE' in os.environ else local_rank
+    backend = os.environ.get('GPBO_DIST_BACKEND', 'nccl')
+    torch.cuda.set_device(dev)
+    if world > 1:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+        else:
+            dist.init_process_group(backend)
+    return world, rank, dev, backend
+
+
+def _max_over_ranks(dt, world, backend):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return dt
+
+
 def secondary(a):
     """The two other GPU configurations of BASELINE.json, same launch contract and JSON shape.
     cfg4: BayesOpt_v4-style loop, theta frozen: EI iterations with incremental append on a 64^4 candidate lattice
@@ -55,12 +84,7 @@ def secondary(a):
     import torch.distributed as dist
     import bayesian_optimization_amd as bo
     from bayesian_optimization_amd import GP, synth
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    world, rank, local_rank, backend = _dist_setup()
 
     def barrier():
         torch.cuda.synchronize()
@@ -69,11 +93,7 @@ def secondary(a):
         torch.cuda.synchronize()
 
     def maxtime(dt):
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-        return dt
+        return _max_over_ranks(dt, world, backend)
 
     gp = GP(local_rank)
     if a.config == 'cfg4':
@@ -158,8 +178,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='cfg2')
-    ap.add_argument('--m', type=int, default=0, help='candidates per GPU (default: the config\'s m)')
-    ap.add_argument('--n', type=int, default=0, help='training points (default: the config\'s n)')
+    ap.add_argument('--candidates', dest='m', type=int, default=0, help='candidates per GPU (default: the config\'s m)')
+    ap.add_argument('--n-train', dest='n', type=int, default=0, help='training points (default: the config\'s n)')
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--iters', type=int, default=200, help='cfg4: EI iterations')
@@ -173,13 +193,7 @@ def main():
     from bayesian_optimization_amd import GP, synth
     from bayesian_optimization_amd import dist as gdist
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    torch.cuda.set_device(local_rank)
+    world, rank, local_rank, backend = _dist_setup()
 
     cfg = dict(synth.CONFIGS[a.config])
     if a.n:
@@ -223,10 +237,7 @@ def main():
         acq_ms += tm['acquire_ms']
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = _max_over_ranks(dt, world, backend)
 
     if rank == 0:
         n = cfg['n']

@@ -432,6 +432,204 @@ void run9(const char* name, const double* A, const double* B, double* C, int n) 
     printf("%-28s packed WPS=%d: %.3f ms  %.2f TFLOP/s  (chk %.6e)\n", name, WPS, best, 2.0 * n * n * n / (best * 1e-3) / 1e12, sum);
 }
 
+// LDS-DMA staging (global_load_lds, 16 B per lane): no VGPR staging and no ds_write.  B image k-major [16][144]
+// (one wave-instruction = one 1 KiB k-row); A image row-major UNPADDED [128][16] with the 16-byte chunks of row x
+// XOR-swizzled by (x>>1)&7 (applied on the global source address and on the fragment read).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glob_void_t;
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void k_gemm_glds(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                                        double* __restrict__ C, int n) {
+    constexpr int TK = 16;
+    constexpr int TILE_A = 128 * 16, TILE_B = TK * LDS_LD;
+    __shared__ __attribute__((aligned(16))) double lds[2 * (TILE_A + TILE_B)];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const double* Ap = A + (long)blockIdx.y * 128 * lda;
+    const double* Bp = B + (long)blockIdx.x * 128;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0, 0, 0, 0};
+    auto stage = [&](int k0, double* la, double* lb) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // A: wave w, pass p covers rows xb..xb+7
+            const int xb = (w * 4 + p) * 8;
+            const int x = xb + (lane >> 3), pc = lane & 7;
+            const int lc = pc ^ ((x >> 1) & 7);
+            const double* ga = Ap + (long)x * lda + k0 + 2 * lc;
+            __builtin_amdgcn_global_load_lds((glob_void_t*)ga, (lds_void_t*)(la + xb * 16), 16, 0, 0);
+            // B: k-row r
+            const int r = w * 4 + p;
+            const double* gb = Bp + (long)(k0 + r) * ldb + 2 * lane;
+            __builtin_amdgcn_global_load_lds((glob_void_t*)gb, (lds_void_t*)(lb + r * LDS_LD), 16, 0, 0);
+        }
+    };
+    stage(0, lds, lds + TILE_A);
+    __syncthreads();
+    int buf = 0;
+    const int ax = wr * 64 + (lane & 15);
+    const int b_off = wc * 64 + (lane & 15) + (lane >> 4) * LDS_LD;
+    for (int k0 = 0; k0 < n; k0 += TK) {
+        const bool has_next = (k0 + TK) < n;
+        double* cur = lds + buf * (TILE_A + TILE_B);
+        double* nxt = lds + (buf ^ 1) * (TILE_A + TILE_B);
+        if (has_next) stage(k0 + TK, nxt, nxt + TILE_A);
+        const double* b_l = cur + TILE_A + b_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[4], bf[4];
+            const int k = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int x = ax + t * 16;
+                af[t] = cur[x * 16 + (((k >> 1) ^ ((x >> 1) & 7)) << 1) + (k & 1)];
+                bf[t] = b_l[kk * 4 * LDS_LD + t * 16];
+            }
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    double* Ct = C + (long)blockIdx.y * 128 * n + (long)blockIdx.x * 128;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ct[(long)(wr * 64 + ta * 16 + (lane >> 4) + 4 * r) * n + wc * 64 + tb * 16 + (lane & 15)] = acc[ta][tb][r];
+}
+
+template <int WPS>
+void run_glds(const char* name, const double* A, const double* B, double* C, int n) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    dim3 grid(n / 128, n / 128);
+    k_gemm_glds<WPS><<<grid, 256>>>(A, n, B, n, C, n);
+    float best = 1e9;
+    for (int it = 0; it < 5; ++it) {
+        (void)hipEventRecord(e0);
+        k_gemm_glds<WPS><<<grid, 256>>>(A, n, B, n, C, n);
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    double sum = 0;
+    std::vector<double> h(1024);
+    (void)hipMemcpy(h.data(), C, 1024 * 8, hipMemcpyDeviceToHost);
+    for (double v : h) sum += v;
+    printf("%-28s glds WPS=%d: %.3f ms  %.2f TFLOP/s  (chk %.6e)\n", name, WPS, best, 2.0 * n * n * n / (best * 1e-3) / 1e12, sum);
+}
+
+// Producer/consumer split: waves 0-3 only read LDS and issue MFMAs; wave 4 issues every LDS-DMA load.
+template <int WPS>
+__global__ __launch_bounds__(320, WPS) void k_gemm_spec(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                                        double* __restrict__ C, int n) {
+    constexpr int TK = 16;
+    constexpr int TILE_A = 128 * 16, TILE_B = TK * LDS_LD;
+    __shared__ __attribute__((aligned(16))) double lds[2 * (TILE_A + TILE_B)];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double* Ap = A + (long)blockIdx.y * 128 * lda;
+    const double* Bp = B + (long)blockIdx.x * 128;
+    auto stage = [&](int k0, double* la, double* lb) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int xb = p * 8;
+            const int x = xb + (lane >> 3), pc = lane & 7;
+            const int lc = pc ^ ((x >> 1) & 7);
+            const double* ga = Ap + (long)x * lda + k0 + 2 * lc;
+            __builtin_amdgcn_global_load_lds((glob_void_t*)ga, (lds_void_t*)(la + xb * 16), 16, 0, 0);
+            const double* gb = Bp + (long)(k0 + p) * ldb + 2 * lane;
+            __builtin_amdgcn_global_load_lds((glob_void_t*)gb, (lds_void_t*)(lb + p * LDS_LD), 16, 0, 0);
+        }
+    };
+    if (w == 4) {
+        stage(0, lds, lds + TILE_A);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = 0; k0 < n; k0 += TK) {
+            double* nxt = lds + (buf ^ 1) * (TILE_A + TILE_B);
+            if (k0 + TK < n) stage(k0 + TK, nxt, nxt + TILE_A);
+            __syncthreads();
+            buf ^= 1;
+        }
+        return;
+    }
+    const int wr = w >> 1, wc = w & 1;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0, 0, 0, 0};
+    __syncthreads();
+    int buf = 0;
+    const int ax = wr * 64 + (lane & 15);
+    const int b_off = wc * 64 + (lane & 15) + (lane >> 4) * LDS_LD;
+    for (int k0 = 0; k0 < n; k0 += TK) {
+        double* cur = lds + buf * (TILE_A + TILE_B);
+        const double* b_l = cur + TILE_A + b_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[4], bf[4];
+            const int k = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int x = ax + t * 16;
+                af[t] = cur[x * 16 + (((k >> 1) ^ ((x >> 1) & 7)) << 1) + (k & 1)];
+                bf[t] = b_l[kk * 4 * LDS_LD + t * 16];
+            }
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    double* Ct = C + (long)blockIdx.y * 128 * n + (long)blockIdx.x * 128;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ct[(long)(wr * 64 + ta * 16 + (lane >> 4) + 4 * r) * n + wc * 64 + tb * 16 + (lane & 15)] = acc[ta][tb][r];
+}
+
+template <int WPS>
+void run_spec(const char* name, const double* A, const double* B, double* C, int n) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    dim3 grid(n / 128, n / 128);
+    k_gemm_spec<WPS><<<grid, 320>>>(A, n, B, n, C, n);
+    float best = 1e9;
+    for (int it = 0; it < 5; ++it) {
+        (void)hipEventRecord(e0);
+        k_gemm_spec<WPS><<<grid, 320>>>(A, n, B, n, C, n);
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    double sum = 0;
+    std::vector<double> h(1024);
+    (void)hipMemcpy(h.data(), C, 1024 * 8, hipMemcpyDeviceToHost);
+    for (double v : h) sum += v;
+    printf("%-28s spec WPS=%d: %.3f ms  %.2f TFLOP/s  (chk %.6e)\n", name, WPS, best, 2.0 * n * n * n / (best * 1e-3) / 1e12, sum);
+}
+
 int main() {
     const int n = 4096;
     std::vector<double> hA((size_t)n * n), hB((size_t)n * n);
@@ -443,6 +641,10 @@ int main() {
     (void)hipMemcpy(A, hA.data(), (size_t)n * n * 8, hipMemcpyHostToDevice);
     (void)hipMemcpy(B, hB.data(), (size_t)n * n * 8, hipMemcpyHostToDevice);
     run<16, 0, 2>("baseline", A, B, C, n);
+    run_glds<2>("LDS-DMA staging", A, B, C, n);
+    run_spec<2>("loader wave + 4 MFMA waves", A, B, C, n);
+    run_spec<1>("loader wave + 4 MFMA waves", A, B, C, n);
+    run_glds<1>("LDS-DMA staging", A, B, C, n);
     run7<2, false>("A row-major in LDS", A, n, B, n, C, n);
     run7<1, false>("A row-major in LDS", A, n, B, n, C, n);
     run7<2, true>("A row-major in LDS", A, n, B, n, C, n);
