@@ -245,6 +245,13 @@ def main():
         flops_per_launch = float(n) * n * (m_per_gpu * a.steps / max(trmm_launches, 1))   # n^2 per candidate x candidates per launch
         avg_launch_s = trmm_ms * 1e-3 / max(trmm_launches, 1)
         achieved = flops_per_launch / avg_launch_s / 1e12
+        traffic = None
+        try:   # HBM bytes per launch of the dominant kernel, from the committed PMC passes of this same workload
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r1_cfg2_traffic.json')))
+            if tr['n_train'] == n and abs(m_per_gpu * a.steps / max(trmm_launches, 1) - tr['candidates_per_launch']) < 1:
+                traffic = tr['fetch_bytes_per_launch'] + tr['write_bytes_per_launch']
+        except Exception:
+            traffic = None
         out = {
             'metric': 'gp_posterior_ei_candidates_per_sec', 'value': total / dt, 'unit': 'candidates/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
@@ -255,7 +262,7 @@ def main():
                        'candidates_per_gpu': m_per_gpu, 'n_train': n, 'd': cfg['d'],
                        'parallelism': 'candidate blocks per rank; all-reduce(max mu) + all-gather(argmax)'},
             'roofline': {'bound': 'mfma', 'kernel': 'k_trmm_sumsq', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
                          'launches': trmm_launches},
             'phases_ms_per_step': {'posterior_total': post_ms / a.steps, 'ks_build': ks_ms / a.steps,
