@@ -57,6 +57,9 @@ struct gpbo_ctx {
     bool inc_valid = false;     // Vres/sres describe the current model and candidates
     std::vector<double> h_xnew;
 
+    // work contexts of the batched likelihood sweep (created on first use, kept for the next call)
+    std::vector<gpbo_ctx*> lml_lanes;
+
     // candidates + outputs
     double* Xs = nullptr;
     int64_t m = 0, m_cap = 0, xs_cap = 0;   // m_cap: outputs (doubles per array); xs_cap: doubles in Xs
@@ -561,6 +564,8 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (gpbo_ctx* l : ctx->lml_lanes) gpbo_destroy(l);
+    ctx->lml_lanes.clear();
     free_model(ctx);
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
                   ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
@@ -1080,11 +1085,12 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     // The settings are independent.  Each lane = a context of its own (work matrices + stream); settings are dealt
     // round-robin over the lanes so that the latency-bound parts of one factorisation (diagonal blocks, panel
     // solves, triangular solves) overlap the MFMA-bound updates of the others.  Lane 0 is the caller's context.
-    int lanes = 4;
+    int lanes = (n_pad <= 1024) ? 8 : 4;      // small problems are launch-latency bound: more streams in flight
     if (const char* e = getenv("GPBO_LML_STREAMS")) lanes = atoi(e);
     lanes = std::max(1, std::min(lanes, std::min<int>(B, 8)));
     std::vector<gpbo_ctx*> lane(lanes, nullptr);
     lane[0] = ctx;
+    for (int l = 1; l < lanes && l - 1 < (int)ctx->lml_lanes.size(); ++l) lane[l] = ctx->lml_lanes[l - 1];
     double *Xraw = nullptr, *th_dev = nullptr, *onll = nullptr, *ograd = nullptr;
     std::vector<double*> gpart(lanes, nullptr);
     int* infos = nullptr;
@@ -1092,7 +1098,6 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         for (int l = 0; l < lanes; ++l) {
             if (lane[l]) hipStreamSynchronize(lane[l]->stream);
             if (gpart[l]) hipFree(gpart[l]);
-            if (l > 0 && lane[l]) gpbo_destroy(lane[l]);
         }
         for (void* p : {(void*)Xraw, (void*)th_dev, (void*)onll, (void*)ograd, (void*)infos})
             if (p) hipFree(p);
@@ -1107,10 +1112,13 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         }                                                                 \
     } while (0)
     for (int l = 0; l < lanes; ++l) {
-        if (l > 0 && gpbo_create(ctx->device, &lane[l]) != GPBO_OK) {
-            ctx->err = "lml_batch: could not create a work context";
-            cleanup();
-            return GPBO_ERR_HIP;
+        if (l > 0 && !lane[l]) {
+            if (gpbo_create(ctx->device, &lane[l]) != GPBO_OK) {
+                ctx->err = "lml_batch: could not create a work context";
+                cleanup();
+                return GPBO_ERR_HIP;
+            }
+            ctx->lml_lanes.push_back(lane[l]);
         }
         gpbo_ctx* c = lane[l];
         int st = ensure_model(c, n_pad, d, true);

@@ -18,6 +18,7 @@ import numpy as np
 
 from . import _lib as L
 from .gp import GP
+from .hyperopt import hypopt, hypopt_wrap  # noqa: F401  (BayesOpt_v4.ipynb:167-186, batched over the starts)
 
 _ctx = {}
 
@@ -211,5 +212,5 @@ def acquisition(mu, yT, sigma):
     return gp.read(mu=False, var=False, acq=True)
 
 
-__all__ = ['distmat_v2', 'kernfcn_v2', 'gprfcn', 'mlefcn', 'expected_improvement', 'polymat', 'gpr_poly', 'y_kriging_v2',
+__all__ = ['distmat_v2', 'kernfcn_v2', 'gprfcn', 'mlefcn', 'expected_improvement', 'hypopt', 'hypopt_wrap', 'polymat', 'gpr_poly', 'y_kriging_v2',
            'acquisition']
