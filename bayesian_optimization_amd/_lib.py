@@ -60,6 +60,7 @@ SIGNATURES = {
     'gpbo_kriging_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, C.c_double, C.c_int32, _dp, _i32p, _dp]),
     'gpbo_set_posterior': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
     'gpbo_kernel_matrix': (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, _dp]),
+    'gpbo_kernel_from_distances': (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, _dp, C.c_int32, _dp]),
     'gpbo_reserve_appends': (C.c_int, [C.c_void_p, C.c_int64]),
     'gpbo_lml_batch': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, _dp, _dp, _i32p]),
     'gpbo_get_factor': (C.c_int, [C.c_void_p, _dp, _dp]),

@@ -1058,6 +1058,42 @@ int gpbo_kernel_matrix(gpbo_ctx* ctx, const double* U, int64_t p, const double* 
     return GPBO_OK;
 }
 
+int gpbo_kernel_from_distances(gpbo_ctx* ctx, const double* Dabs, int32_t d, int64_t p, int64_t q, const double* theta,
+                               int32_t kernel, double* K_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!Dabs || !theta || !K_out || p <= 0 || q <= 0 || d <= 0 || d > MAX_D) BADARG("kernel_from_distances: bad arguments");
+    if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN52) BADARG("kernel_from_distances: unknown kernel");
+    for (int t = 0; t < d; ++t)
+        if (!(theta[t] != 0.0) || !std::isfinite(theta[t])) BADARG("kernel_from_distances: theta entries must be finite and non-zero");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t pq = (size_t)p * q;
+    double *dd = nullptr, *dk = nullptr, *dth = nullptr;
+    auto cleanup = [&]() {
+        for (void* ptr : {(void*)dd, (void*)dk, (void*)dth})
+            if (ptr) hipFree(ptr);
+    };
+    std::vector<double> ith(d);
+    for (int t = 0; t < d; ++t) ith[t] = 1.0 / theta[t];
+    if (hipMalloc((void**)&dd, pq * d * 8) != hipSuccess || hipMalloc((void**)&dk, pq * 8) != hipSuccess ||
+        hipMalloc((void**)&dth, (size_t)d * 8) != hipSuccess) {
+        cleanup();
+        ctx->err = "kernel_from_distances: hipMalloc failed";
+        return GPBO_ERR_HIP;
+    }
+    hipMemcpyAsync(dd, Dabs, pq * d * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(dth, ith.data(), (size_t)d * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipLaunchKernelGGL(k_kernel_from_absdiff, dim3((unsigned)((pq + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)dd,
+                       (long)pq, (int)d, (const double*)dth, kernel, dk);
+    hipError_t e1 = hipMemcpyAsync(K_out, dk, pq * 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        ctx->err = std::string("kernel_from_distances: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
+        return GPBO_ERR_HIP;
+    }
+    return GPBO_OK;
+}
+
 int gpbo_reserve_appends(gpbo_ctx* ctx, int64_t max_appends) {
     if (!ctx) return GPBO_ERR_BAD_ARG;
     if (max_appends < 0) BADARG("reserve_appends: negative");

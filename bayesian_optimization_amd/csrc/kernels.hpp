@@ -937,6 +937,20 @@ __global__ __launch_bounds__(256) void k_cross_kernel(const double* __restrict__
     K[i * q + j] = kern_eval(D, kernel);
 }
 
+// kernfcn_v2 on explicit per-dimension |difference| matrices (the notebooks' Daa list): Dabs is [d][p*q].
+__global__ __launch_bounds__(256) void k_kernel_from_absdiff(const double* __restrict__ Dabs, long pq, int d,
+                                                             const double* __restrict__ invtheta, int kernel,
+                                                             double* __restrict__ K) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= pq) return;
+    double D = 0.0;
+    for (int t = 0; t < d; ++t) {
+        const double df = Dabs[(long)t * pq + e] * invtheta[t];
+        D += df * df;
+    }
+    K[e] = kern_eval(D, kernel);
+}
+
 __global__ void k_set_scalar(double* dst, double v) { *dst = v; }
 __global__ void k_copy_scalar(double* dst, const double* src) { *dst = *src; }
 

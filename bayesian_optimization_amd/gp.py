@@ -172,6 +172,15 @@ class GP:
                                                  int(kernel), L.dptr(K)))
         return K
 
+    def kernel_from_distances(self, Daa, theta, kernel=L.KERNEL_RBF):
+        """kernfcn_v2 on a list of d per-dimension |difference| matrices, each (p, q)."""
+        D = _f64(np.stack([np.asarray(a, dtype=np.float64) for a in Daa]), 3)
+        th = _f64(np.asarray(theta).reshape(-1)[:D.shape[0]], 1)
+        K = np.empty(D.shape[1:])
+        self._check(self._lib.gpbo_kernel_from_distances(self._h, L.dptr(D), D.shape[0], D.shape[1], D.shape[2], L.dptr(th),
+                                                         int(kernel), L.dptr(K)))
+        return K
+
     def reserve_appends(self, max_appends: int):
         """Room for appended points; call before fit(variant=VARIANT_SINGLE)."""
         self._check(self._lib.gpbo_reserve_appends(self._h, int(max_appends)))

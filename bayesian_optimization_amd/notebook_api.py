@@ -101,10 +101,8 @@ def distmat_v2(u, v):
 def kernfcn_v2(Daa, theta):
     if isinstance(Daa, DistList):
         return _gp('aux').kernel_matrix(Daa.u, Daa.v, np.asarray(theta, dtype=np.float64)[:len(Daa)])
-    # plain list of |difference| matrices (the notebook's own format): rebuild point sets that realise them is not
-    # possible in general, so evaluate the formula of :119-124 on the device from 1-D embeddings when the list came
-    # from distance_matrix of coordinates; otherwise the caller should pass DistList.
-    raise TypeError('kernfcn_v2 needs the object returned by distmat_v2 of this module')
+    # a plain list of |difference| matrices (what the reference's own distmat_v2 returns)
+    return _gp('aux').kernel_from_distances(list(Daa), theta)
 
 
 def gprfcn(xTest, xTrain, yTrain, theta, sigmaY):

@@ -147,6 +147,11 @@ int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64
 int gpbo_kernel_matrix(gpbo_ctx* ctx, const double* U, int64_t p, const double* V, int64_t q, int32_t d,
                        const double* theta, int32_t kernel, double* K_out);
 
+/* kernfcn_v2(Daa, theta) on an explicit list of per-dimension |u_i - v_j| matrices (the notebooks' Daa,
+ * BayesOpt_v4.ipynb:119-124): Dabs is d stacked (p,q) matrices, K_out is (p,q). */
+int gpbo_kernel_from_distances(gpbo_ctx* ctx, const double* Dabs, int32_t d, int64_t p, int64_t q,
+                               const double* theta, int32_t kernel, double* K_out);
+
 /* Room for max_appends appended points; call BEFORE gpbo_fit (single-factor variant).  The next
  * gpbo_posterior then keeps V = L^-1 Ks^T (rows x candidates, 8 bytes each) resident in HBM. */
 int gpbo_reserve_appends(gpbo_ctx* ctx, int64_t max_appends);

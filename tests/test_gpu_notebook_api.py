@@ -69,6 +69,9 @@ def test_mlefcn_distmat_kernfcn():
         assert abs(v - g['nll_sigma005'][i, j]) <= 1e-10 * abs(g['nll_sigma005'][i, j])
     K = nb.kernfcn_v2(Daa, np.array([0.3, 0.2]))
     assert relmax(K, o.kernel_matrix(xT, xT, np.array([0.3, 0.2]))) <= 1e-14
+    plain = [np.abs(xT[:, i][:, None] - xT[:7, i][None, :]) for i in range(2)]      # a plain list, as the reference's distmat_v2 builds
+    K2 = nb.kernfcn_v2(plain, np.array([0.3, 0.2]))
+    assert K2.shape == (94, 7) and relmax(K2, o.kernel_matrix(xT, xT[:7], np.array([0.3, 0.2]))) <= 1e-14
 
 
 @pytest.mark.parametrize('name', golden_names('g7'))
@@ -110,3 +113,31 @@ def test_multistart_hyperparameter_fit_follows_the_reference_update_rule():
     theta = nb.hypopt_wrap(nruns, max_its, alpha, beta, 'component', 'normal', xT, yT, None, 0.05, x0=x0)
     best = int(np.argmin([c[-1] for c in c_hist]))
     assert np.array_equal(theta, w_hist[best][-1])
+
+
+def test_continuous_acquisition_maximisation_improves_on_the_grid(gp0):
+    """Grid sweep -> top-k seeds -> batched compass search (the fminsearch step of GP/BayesOpt_v2b.m:41-46):
+    the refined UCB / EI is at least the grid maximum and agrees with the oracle evaluated at the refined point."""
+    import bayesian_optimization_amd as bo
+    from bayesian_optimization_amd import acqopt
+    n, d = 60, 2
+    X = o.splitmix64_uniform(31, n * d).reshape(n, d)
+    y = np.sin(5 * X[:, 0]) * np.cos(3 * X[:, 1]) + X[:, 0]
+    theta = np.array([0.25, 0.3])
+    g1 = np.linspace(0, 1, 40)
+    grid = np.array([[a, b] for a in g1 for b in g1])
+    gp0.fit(X, y, theta, 0.02)
+    gp0.set_candidates(grid)
+    mu_max = gp0.posterior()
+    for acq, kappa in ((bo.ACQ_UCB, 1.0), (bo.ACQ_EI, 0.01)):
+        idx, best = gp0.acquire(acq, kappa, bo.INCUMBENT_GIVEN, mu_max)
+        vals = gp0.read(mu=False, var=False, acq=True)
+        seeds = grid[acqopt.top_k(vals, 8)]
+        assert np.array_equal(seeds[0], grid[idx])
+        x, v, allx, allv = acqopt.maximize_acquisition(gp0, seeds, 0.0, 1.0, acq, kappa, incumbent=mu_max)
+        assert v >= best and np.all((x >= 0) & (x <= 1))
+        mu_o, var_o, _ = o.gprfcn_diag(x[None, :], X, y, theta, 0.02)
+        ref = o.ucb(mu_o, var_o, kappa) if acq == bo.ACQ_UCB else o.expected_improvement(mu_o, var_o, kappa, incumbent=mu_max)
+        assert abs(float(np.squeeze(ref)) - v) <= 1e-8 * max(abs(v), 1e-12)
+        gp0.set_candidates(grid)          # restore the grid as the resident set for the next acquisition
+        gp0.posterior()
