@@ -131,3 +131,64 @@ class ShardedSweep:
         idx, best = self.gp.acquire(acq, kappa, 2, mu_max)          # incumbent given = global max(Mu)
         gbest, gidx = global_argmax(best, idx, self.offset, self.gp.device)
         return gidx, gbest, mu_max
+
+
+def allreduce_sum(vec, device=None):
+    """Element-wise sum over ranks of a small float64 vector (returned as a NumPy array)."""
+    v = np.ascontiguousarray(vec, dtype=np.float64)
+    if not _is_dist():
+        return v.copy()
+    t = torch.from_numpy(v.copy()).to(_exchange_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+class ShardedLoop:
+    """Frozen-theta BO loop (single-factor posterior, GP/BayesOptFcn_v1.m:73-83) with the candidate rows -- and with them the
+    resident V = W Ks^T -- split over ranks.  Every rank holds the same small model and applies the same border-append, so
+    the model needs no exchange; per iteration the data path exchanges max(Mu) (one double), the per-rank argmax pairs and
+    the d coordinates of the chosen candidate."""
+
+    def __init__(self, gp, candidates_local, offset: int = 0):
+        self.gp = gp
+        self.X = np.ascontiguousarray(candidates_local, dtype=np.float64)
+        self.offset = int(offset)
+        gp.set_candidates(self.X)
+        self.mu_max = allreduce_max(gp.posterior(), gp.device)
+
+    def propose(self, acq=0, kappa=0.01):
+        """(global index, acquisition value, coordinates) of the next point; identical on every rank."""
+        idx, best = self.gp.acquire(acq, kappa, 2, self.mu_max)
+        gbest, gidx = global_argmax(best, idx, self.offset, self.gp.device)
+        mine = self.offset <= gidx < self.offset + len(self.X)
+        x = allreduce_sum(self.X[gidx - self.offset] if mine else np.zeros(self.X.shape[1]), self.gp.device)
+        return gidx, gbest, x
+
+    def observe(self, x_new, y_new):
+        self.mu_max = allreduce_max(self.gp.append(x_new, y_new), self.gp.device)
+        return self.mu_max
+
+
+def sharded_lml(gp, xTrain, yTrain, thetas, sigmas, kernel=0, grad=True):
+    """-logL (and gradient) of B hyper-parameter settings, settings split over ranks in contiguous blocks; every rank
+    returns the full (nll (B,), grad (B,d) or None, status (B,)).  The settings are independent: the only exchange is
+    the gather of the results."""
+    thetas = np.ascontiguousarray(thetas, dtype=np.float64)
+    sigmas = np.ascontiguousarray(sigmas, dtype=np.float64).reshape(-1)
+    B, d = thetas.shape
+    rank = dist.get_rank() if _is_dist() else 0
+    world = dist.get_world_size() if _is_dist() else 1
+    lo, hi = shard_range(B, rank, world)
+    buf = np.zeros((B, d + 2))
+    if hi > lo:
+        res = gp.lml_batch(xTrain, yTrain, thetas[lo:hi], sigmas[lo:hi], kernel=kernel, grad=grad)
+        nll, g, stat = res if grad else (res[0], None, res[1])
+        buf[lo:hi, 0] = np.where(np.isnan(nll), 0.0, nll)          # NaN (failed setting) travels as status, not through the sum
+        buf[lo:hi, 1] = stat
+        if grad:
+            buf[lo:hi, 2:] = np.where(np.isnan(g), 0.0, g)
+    buf = allreduce_sum(buf.reshape(-1), gp.device).reshape(B, d + 2)
+    stat = buf[:, 1].astype(np.int32)
+    nll = np.where(stat != 0, np.nan, buf[:, 0])
+    g = np.where((stat != 0)[:, None], np.nan, buf[:, 2:]) if grad else None
+    return nll, g, stat

@@ -97,27 +97,35 @@ def secondary(a):
 
     gp = GP(local_rank)
     if a.config == 'cfg4':
-        d, side, n0 = 4, 64, 16
+        from bayesian_optimization_amd import dist as gdist
+        d, side, n0 = 4, a.side, 16
         g1 = (np.arange(side) + 0.5) / side
-        grid = np.stack(np.meshgrid(g1, g1, g1, g1, indexing='ij'), -1).reshape(-1, d)     # lexicographic, as the notebooks' nested loops
+        m_total = side ** d
+        sharded = world > 1 and not a.replicas       # candidate rows (and the resident V) split over the ranks: one loop, strong scaling
+        lo, hi = gdist.shard_range(m_total, rank, world) if sharded else (0, m_total)
+        # lexicographic order, as the notebooks' nested loops; built per block from the flat index
+        ii = np.arange(lo, hi)
+        grid = np.stack([g1[(ii // side ** (d - 1 - k)) % side] for k in range(d)], -1)
         f = lambda x: np.exp(-8 * np.sum((x - 0.37) ** 2, -1)) + 0.5 * np.exp(-20 * np.sum((x - 0.8) ** 2, -1))
-        X0 = synth.uniform(4 + rank, n0 * d).reshape(n0, d)          # every rank runs its own independent loop (replicas)
+        X0 = synth.uniform(4 if sharded else 4 + rank, n0 * d).reshape(n0, d)     # replicas: every rank runs its own independent loop
         iters = a.iters
         gp.reserve_appends(iters + a.warmup)
         gp.fit(X0, f(X0), np.full(d, 0.25), 1e-2, variant=bo.VARIANT_SINGLE)
-        gp.set_candidates(grid)
-        gp.posterior()
+        loop = gdist.ShardedLoop(gp, grid, lo)
         m = len(grid)
         sweep_ms, bytes_alg = 0.0, 0.0
+        picked = []
         for it in range(a.warmup):
-            jj, _ = gp.acquire(bo.ACQ_EI, 0.01)
-            gp.append(grid[jj], float(f(grid[jj])))
+            jj, _, x = loop.propose(bo.ACQ_EI, 0.01)
+            picked.append(jj)
+            loop.observe(x, float(f(x)))
         barrier()
         t0 = time.perf_counter()
         for it in range(iters):
-            jj, ei = gp.acquire(bo.ACQ_EI, 0.01)
+            jj, ei, x = loop.propose(bo.ACQ_EI, 0.01)
+            picked.append(jj)
             n_before = gp.n
-            gp.append(grid[jj], float(f(grid[jj])))
+            loop.observe(x, float(f(x)))
             tm = gp.timings()
             sweep_ms += tm['append_sweep_ms']
             bytes_alg += m * (8.0 * n_before + 8 + 32 + 8 * d)     # V read + new V row + (mu, var r/w; sum v^2 r/w) + candidates
@@ -125,13 +133,17 @@ def secondary(a):
         dt = maxtime(time.perf_counter() - t0)
         if rank == 0:
             achieved = bytes_alg / (sweep_ms * 1e-3) / 1e9
+            loops = 1 if sharded else world
             print(json.dumps({
-                'metric': 'bo_loop_iterations_per_sec', 'value': world * iters / dt, 'unit': 'iterations/s', 'n_gpus': world,
-                'steps': iters, 'warmup': a.warmup, 'ms_per_step': dt / iters * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                'metric': 'bo_loop_iterations_per_sec', 'value': loops * iters / dt, 'unit': 'iterations/s', 'n_gpus': world,
+                'steps': iters, 'warmup': a.warmup, 'ms_per_step': dt / iters * 1e3, 'higher_is_better': True,
+                'scaling': 'strong' if sharded else 'weak',
                 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                 'config': {'workload': 'cfg4: %d EI iterations, incremental append (theta frozen, single-factor posterior), '
-                                       '64^4 = %d candidate lattice, d=4, n0=%d, sigmaY=1e-2; one independent loop per GPU' % (iters, m, n0),
-                           'n_final': gp.n, 'best_y': float(gp.y_max)},
+                                       '%d^4 = %d candidate lattice, d=4, n0=%d, sigmaY=1e-2; %s'
+                                       % (iters, side, m_total, n0, 'candidate rows and resident V split over the GPUs, one loop'
+                                          if sharded else 'one independent loop per GPU'),
+                           'n_final': gp.n, 'best_y': float(gp.y_max), 'picked_head': [int(j) for j in picked[:16]]},
                 'roofline': {'bound': 'hbm', 'kernel': 'k_append_sweep', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': achieved / 8000.0, 'traffic': None, 'avg_launch_ms': sweep_ms / iters,
                              'bytes_per_launch_avg': bytes_alg / iters}}), flush=True)
@@ -183,6 +195,8 @@ def main():
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--iters', type=int, default=200, help='cfg4: EI iterations')
+    ap.add_argument('--side', type=int, default=64, help='cfg4: points per axis of the candidate lattice')
+    ap.add_argument('--replicas', action='store_true', help='cfg4 with several GPUs: independent loops instead of one sharded loop')
     ap.add_argument('--settings', type=int, default=0, help='cfg5: settings per GPU (default 256 / gpus)')
     a = ap.parse_args()
     if a.config in ('cfg4', 'cfg5'):

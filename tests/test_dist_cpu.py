@@ -68,3 +68,47 @@ def test_pick_best_is_first_occurrence_and_ignores_nan():
     assert gdist.pick_best([1.0, 3.0, 3.0, float('nan')], [40, 30, 20, 10]) == (3.0, 20)
     v, i = gdist.pick_best([float('nan')], [5])
     assert np.isnan(v) and i == 5
+
+
+class _FakeGP:
+    """Stands in for a GPU context: -logL of a setting is a fixed function of the setting; one setting 'fails'."""
+    device = None
+
+    def lml_batch(self, X, y, thetas, sigmas, kernel=0, grad=False):
+        nll = thetas.sum(1) + sigmas
+        stat = (sigmas > 0.9).astype(np.int32)
+        nll = np.where(stat != 0, np.nan, nll)
+        g = np.where((stat != 0)[:, None], np.nan, 2.0 * thetas)
+        return (nll, g, stat) if grad else (nll, stat)
+
+
+def _lml_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        B, d = 7, 3
+        thetas = np.arange(B * d, dtype=np.float64).reshape(B, d) / 10
+        sigmas = np.linspace(0.1, 1.0, B)
+        nll, g, stat = gdist.sharded_lml(_FakeGP(), None, None, thetas, sigmas, grad=True)
+        q.put((rank, nll, g, stat))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_lml_gathers_every_setting():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lml_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    B, d = 7, 3
+    thetas = np.arange(B * d, dtype=np.float64).reshape(B, d) / 10
+    sigmas = np.linspace(0.1, 1.0, B)
+    nll, g, stat = _FakeGP().lml_batch(None, None, thetas, sigmas, grad=True)
+    for r in res:
+        assert np.array_equal(r[1], nll, equal_nan=True) and np.array_equal(r[2], g, equal_nan=True) and np.array_equal(r[3], stat)

@@ -33,3 +33,47 @@ def test_two_rank_sweep_equals_single_process(gp0):
     idx, best = gp0.acquire(0, cfg['kappa'])
     assert res['argmax']['index'] == idx and res['argmax']['ei'] == best and res['argmax']['mu_max'] == mu_max
     assert idx >= 0 and np.isfinite(best)
+
+
+def test_two_rank_sharded_loop_picks_the_same_points(gp0):
+    """BO loop with the lattice (and the resident V) split over two ranks: the sequence of chosen candidates equals the
+    one-process loop's, index for index."""
+    import bayesian_optimization_amd as bo
+    from bayesian_optimization_amd import synth, dist as gdist
+    side, iters, d, n0 = 16, 12, 4, 16
+    env = dict(os.environ, GPBO_DIST_BACKEND='gloo', GPBO_FORCE_DEVICE='0', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29543', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', 'cfg4', '--side', str(side),
+           '--iters', str(iters), '--warmup', '0']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert res['n_gpus'] == 2 and res['scaling'] == 'strong'
+    g1 = (np.arange(side) + 0.5) / side
+    grid = np.stack(np.meshgrid(g1, g1, g1, g1, indexing='ij'), -1).reshape(-1, d)
+    f = lambda x: np.exp(-8 * np.sum((x - 0.37) ** 2, -1)) + 0.5 * np.exp(-20 * np.sum((x - 0.8) ** 2, -1))
+    X0 = synth.uniform(4, n0 * d).reshape(n0, d)
+    gp0.reserve_appends(iters)
+    gp0.fit(X0, f(X0), np.full(d, 0.25), 1e-2, variant=bo.VARIANT_SINGLE)
+    loop = gdist.ShardedLoop(gp0, grid, 0)
+    picked = []
+    for _ in range(iters):
+        jj, _, x = loop.propose(bo.ACQ_EI, 0.01)
+        assert np.array_equal(x, grid[jj])
+        picked.append(jj)
+        loop.observe(x, float(f(x)))
+    assert res['config']['picked_head'] == picked
+    assert res['config']['best_y'] == gp0.y_max
+
+
+def test_sharded_lml_single_process_equals_lml_batch(gp0):
+    from bayesian_optimization_amd import dist as gdist
+    import oracle.gp_oracle as o
+    X = o.splitmix64_uniform(77, 200 * 3).reshape(200, 3)
+    y = np.sin(X.sum(1))
+    th = np.array([[0.3, 0.4, 0.5], [0.2, 0.2, 0.2], [0.6, 0.5, 0.4]])
+    sg = np.array([0.1, 0.05, 0.2])
+    a = gp0.lml_batch(X, y, th, sg, grad=True)
+    b = gdist.sharded_lml(gp0, X, y, th, sg, grad=True)
+    for p, q in zip(a, b):
+        assert np.array_equal(p, q)
