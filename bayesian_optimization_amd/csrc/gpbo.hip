@@ -32,6 +32,10 @@ struct EvRec {
 struct gpbo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t pstream = nullptr;          // high-priority stream of the Cholesky panel work (created on first use)
+    hipStream_t bstream = nullptr;          // bulk trailing updates beside it; CU-masked so a CU per XCD stays free for the diagonal blocks
+    std::vector<hipEvent_t> sync_ev;        // cross-stream ordering events (no timing), reused by every factorisation
+    bool lookahead = true;                  // false on the work contexts of a multi-lane likelihood sweep
     std::string err;
     int64_t info = 0;
 
@@ -231,28 +235,125 @@ int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, doub
 }
 
 // Right-looking blocked Cholesky, panels of 128 columns processed in groups of CHOL_GROUP:
-// inside a group each panel is first brought up to date with the group's earlier panels (a narrow
-// update of one block column), factored (diagonal block in LDS, panel solve by the inverted
-// diagonal block); after the group the whole trailing matrix is updated once with K = 128*group.
-constexpr int CHOL_GROUP = 4;
+// inside a group each panel is factored (diagonal block in one workgroup, panel solve by the inverted diagonal
+// block) and applied to the group's remaining block columns; after the group the whole trailing matrix is
+// updated once with K = 128*group.
+int chol_group(int nb) {
+    if (const char* e = getenv("GPBO_CHOL_GROUP")) return std::max(1, atoi(e));
+    return nb >= 192 ? 8 : 4;      // large n: the panel stream is hidden, a longer K makes the bulk update more efficient
+}
+
+// F(group): the latency-bound part.  Needs the group's block columns up to date.
+// excl: the diagonal-block kernel asks for a CU of its own (see k_potrf_diag).
+void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, int p0, int g, bool excl) {
+    const long ld = ctx->n_pad;
+    const int nb = (int)ctx->nb;
+    for (int q = p0; q < p0 + g; ++q) {
+        if (excl) hipLaunchKernelGGL(k_potrf_diag_excl, dim3(1), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev);
+        else hipLaunchKernelGGL(k_potrf_diag_shared, dim3(1), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev);
+        if (q + 1 < nb) hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1), dim3(GEMM_THREADS), 0, st, A, ld, q, ctx->Dinv);
+        const int rest = p0 + g - 1 - q;      // the group's block columns right of q take panel q at once (K = 128):
+        if (rest > 0)                         // more tiles per launch and a shorter chain than one growing-K update per column
+            hipLaunchKernelGGL(k_syrk_update<false>, dim3(rest, nb - q - 1), dim3(GEMM_THREADS), 0, st, A, ld, q + 1, q + 1, q * PB, PB);
+    }
+}
+
+hipEvent_t sync_event(gpbo_ctx* ctx, size_t i) {
+    while (ctx->sync_ev.size() <= i) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        ctx->sync_ev.push_back(e);
+    }
+    return ctx->sync_ev[i];
+}
+
+// Two-stream form (lookahead).  Bulk stream, per group g, in order: U_next(g) = group g's update of the NEXT group's
+// block columns, then U_rest(g) = its update of everything right of them.  Panel stream (high priority): F(g+1) as
+// soon as U_next(g) is done, i.e. beside U_rest(g); U_next(g+1) waits for F(g+1).  Every update of a tile is issued on
+// the bulk stream in factorisation order; the panel stream touches only the block columns of its own group.
+//
+// Where the diagonal-block kernel runs meanwhile (measured at n = 32768, trailing update in flight): sharing a CU with
+// a tile workgroup it takes 0.7 ms instead of 0.19 ms (1.4 ms when held to the 256 registers that fit beside a tile
+// wave), and the panel stream becomes the critical path; asking for a CU of its own it waits for the whole update
+// (1.6 ms, up to 12 ms) unless the bulk stream's CU mask leaves CUs free.  A mask that leaves out one CU per XCD
+// costs the bulk stream 13-19 % (the workgroup distributor deals evenly over shader engines, the short one sets
+// the pace) and is still the fastest combination at every size measured: masked bulk stream, exclusive diagonal
+// kernel.  GPBO_CHOL_MASK=0 selects the unmasked stream with the co-resident kernel.
+int launch_cholesky_lookahead(gpbo_ctx* ctx, double* A, int* info_dev) {
+    const long ld = ctx->n_pad;
+    const int nb = (int)ctx->nb;
+    bool masked = true;
+    if (const char* e = getenv("GPBO_CHOL_MASK")) masked = atoi(e) != 0;
+    if (!ctx->pstream) {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));     // hi = numerically lowest = greatest priority
+        HIPCHK(hipStreamCreateWithPriority(&ctx->pstream, hipStreamNonBlocking, hi));
+    }
+    if (masked && !ctx->bstream) {
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDeviceProperties(&pr, ctx->device));
+        std::vector<uint32_t> mask((pr.multiProcessorCount + 31) / 32, 0xffffffffu);
+        mask[0] &= ~0xffu;                                     // mask bits are dealt round-robin over the 8 XCDs: one CU of each
+        if (hipExtStreamCreateWithCUMask(&ctx->bstream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&ctx->bstream, hipStreamNonBlocking));
+        }
+    }
+    hipStream_t B = masked ? ctx->bstream : ctx->stream, P = ctx->pstream;
+    size_t ne = 0;
+    hipEvent_t ev = sync_event(ctx, ne++);
+    HIPCHK(hipEventRecord(ev, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(P, ev, 0));
+    if (masked) HIPCHK(hipStreamWaitEvent(B, ev, 0));
+    const int G = chol_group(nb);
+    for (int p0 = 0; p0 < nb; p0 += G) {
+        const int g = std::min(G, nb - p0);
+        chol_factor_group(P, ctx, A, info_dev, p0, g, masked);
+        const int c1 = p0 + g;                      // first block right of the group
+        const int T = nb - c1;
+        if (T <= 0) break;
+        ev = sync_event(ctx, ne++);                 // F(g) done
+        HIPCHK(hipEventRecord(ev, P));
+        HIPCHK(hipStreamWaitEvent(B, ev, 0));
+        const int gn = std::min(G, T);              // width of the next group
+        hipLaunchKernelGGL(k_syrk_update<false>, dim3(gn, T), dim3(GEMM_THREADS), 0, B, A, ld, c1, c1, p0 * PB, g * PB);
+        ev = sync_event(ctx, ne++);                 // U_next(g) done: the next group's columns are up to date
+        HIPCHK(hipEventRecord(ev, B));
+        HIPCHK(hipStreamWaitEvent(P, ev, 0));
+        const int T2 = T - gn;
+        if (T2 > 0)
+            hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T2 * (T2 + 1) / 2)), dim3(GEMM_THREADS), 0, B, A, ld, c1 + gn,
+                               c1 + gn, p0 * PB, g * PB);
+    }
+    ev = sync_event(ctx, ne++);
+    HIPCHK(hipEventRecord(ev, P));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
+    if (masked) {
+        ev = sync_event(ctx, ne++);
+        HIPCHK(hipEventRecord(ev, B));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
+    }
+    return GPBO_OK;
+}
+
 int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     Scope s(ctx, T_CHOL);
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
-    for (int p0 = 0; p0 < nb; p0 += CHOL_GROUP) {
-        const int g = std::min(CHOL_GROUP, nb - p0);
-        for (int q = p0; q < p0 + g; ++q) {
-            if (q > p0)   // block column q, rows q..nb-1, against panels p0..q-1
-                hipLaunchKernelGGL(k_syrk_update, dim3(1, nb - q), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, q, q, p0 * PB,
-                                   (q - p0) * PB);
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(POTRF_THREADS), 0, ctx->stream, A, ld, q, ctx->Dinv, info_dev);
-            if (q + 1 < nb)
-                hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, q, ctx->Dinv);
+    const int G = chol_group(nb);
+    bool la = ctx->lookahead && nb > 3 * G;
+    if (const char* e = getenv("GPBO_CHOL_LOOKAHEAD")) la = la && atoi(e) != 0;
+    if (la) {
+        CHK(launch_cholesky_lookahead(ctx, A, info_dev));
+    } else {
+        for (int p0 = 0; p0 < nb; p0 += G) {
+            const int g = std::min(G, nb - p0);
+            chol_factor_group(ctx->stream, ctx, A, info_dev, p0, g, true);
+            const int T = nb - (p0 + g);
+            if (T > 0)
+                hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T * (T + 1) / 2)), dim3(GEMM_THREADS), 0, ctx->stream, A, ld,
+                                   p0 + g, p0 + g, p0 * PB, g * PB);
         }
-        const int T = nb - (p0 + g);
-        if (T > 0)
-            hipLaunchKernelGGL(k_syrk_update, dim3(T, T), dim3(GEMM_THREADS), 0, ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB,
-                               g * PB);
     }
     dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4));
     hipLaunchKernelGGL(k_zero_upper, grid, dim3(256), 0, ctx->stream, A, (int)ctx->n_pad);
@@ -284,7 +385,7 @@ int launch_inverse(gpbo_ctx* ctx, const double* L, double* W, double* T) {
     hipLaunchKernelGGL(k_inv_copy_diag, dim3(nb), dim3(256), 0, ctx->stream, W, ld, ctx->Dinv);
     for (int sb = 1; sb < nb; sb *= 2) {
         const int pairs = (nb + 2 * sb - 1) / (2 * sb);
-        dim3 grid(sb, sb, pairs);
+        dim3 grid(sb, sb, pairs);      // step1: (ib, jb), step2: (jb, reversed ib): the slow index orders tiles longest first
         hipLaunchKernelGGL(k_inv_step1, grid, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb);
         hipLaunchKernelGGL(k_inv_step2, grid, dim3(GEMM_THREADS), 0, ctx->stream, W, (const double*)T, ld, sb, nb);
     }
@@ -573,6 +674,12 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     for (void* p : ps)
         if (p) hipFree(p);
     for (auto e : ctx->pool) hipEventDestroy(e);
+    for (hipStream_t st : {ctx->pstream, ctx->bstream})
+        if (st) {
+            hipStreamSynchronize(st);
+            hipStreamDestroy(st);
+        }
+    for (hipEvent_t e : ctx->sync_ev) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1121,7 +1228,15 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     // The settings are independent.  Each lane = a context of its own (work matrices + stream); settings are dealt
     // round-robin over the lanes so that the latency-bound parts of one factorisation (diagonal blocks, panel
     // solves, triangular solves) overlap the MFMA-bound updates of the others.  Lane 0 is the caller's context.
-    int lanes = (n_pad <= 1024) ? 8 : 4;      // small problems are launch-latency bound: more streams in flight
+    // Eight lanes measure 5-6 % faster than four at n = 16384; a lane holds three n_pad^2 matrices, so large problems
+    // take as many as fit in half of the free memory.
+    int lanes = 8;
+    {
+        size_t free_b = 0, total_b = 0;
+        const double per_lane = 3.0 * 8.0 * (double)n_pad * (double)n_pad;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            lanes = (int)std::max(1.0, std::min(8.0, std::floor(0.5 * (double)free_b / per_lane)));
+    }
     if (const char* e = getenv("GPBO_LML_STREAMS")) lanes = atoi(e);
     lanes = std::max(1, std::min(lanes, std::min<int>(B, 8)));
     std::vector<gpbo_ctx*> lane(lanes, nullptr);
@@ -1137,6 +1252,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         }
         for (void* p : {(void*)Xraw, (void*)th_dev, (void*)onll, (void*)ograd, (void*)infos})
             if (p) hipFree(p);
+        ctx->lookahead = true;         // lane 0 is the caller's context
     };
 #define LCHK(expr)                                                        \
     do {                                                                  \
@@ -1163,6 +1279,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             cleanup();
             return st;
         }
+        c->lookahead = (lanes == 1);   // several lanes already overlap each other's panel work
         c->fitted = false;             // the model buffers are work space here
         c->have_posterior = false;
         c->have_factor = false;
@@ -1209,7 +1326,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
                 st = launch_inverse(c, c->bufA, c->bufW, c->bufB);
                 if (st == GPBO_OK) {
                     hipMemsetAsync(gpart[b % lanes], 0, (size_t)ntiles * GRAD_D * 8, c->stream);
-                    hipLaunchKernelGGL(k_lml_grad_tiles, dim3(nb, nb), dim3(GEMM_THREADS), 0, c->stream, (const double*)c->bufW,
+                    hipLaunchKernelGGL(k_lml_grad_tiles, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(GEMM_THREADS), 0, c->stream, (const double*)c->bufW,
                                        (long)n_pad, (const double*)c->Xts, (int)n, (int)n_pad, (int)d, (const double*)c->alpha1,
                                        (const double*)c->params, gpart[b % lanes], nb);
                 }

@@ -19,6 +19,16 @@ constexpr int PARAMS_DOUBLES = 64;
 constexpr int MAX_TREND = 10;
 constexpr int MAX_D = 32;
 
+// Lower-triangle tile index t = i (i + 1) / 2 + j, 0 <= j <= i  ->  (i, j).  Launching exactly the lower tiles
+// instead of a square grid whose upper half exits at once is worth 10-35 % on the triangular updates: an empty
+// workgroup still occupies a dispatch slot and its 72 KiB of LDS for a moment.
+__device__ __forceinline__ void tri_decode(int t, int& i, int& j) {
+    i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long)(i + 1) * (i + 2) / 2 <= t) ++i;
+    while ((long)i * (i + 1) / 2 > t) --i;
+    j = t - (int)((long)i * (i + 1) / 2);
+}
+
 __device__ __forceinline__ double kern_eval(double D, int kernel) {
     if (kernel == 0) return exp(-0.5 * D);
     const double r = sqrt(D);
@@ -66,10 +76,15 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
 // Writes L (lower, zeros above) back into A and inv(L) (lower, zeros above) into Dinv.
 // info: first failing 1-based global row (pivot <= 0 or NaN), set once.
 constexpr int POTRF_THREADS = 256;
-constexpr int PLD = 129;   // LDS pitch of the copy of L used by the inverse (column reads, 4 rows per wave)
-__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
-                                                              int* __restrict__ info) {
-    __shared__ double S[PB * PLD];      // L, row-major, for the inverse phase
+// The inverse phase reads L from a packed lower-triangular LDS copy (row r starts at r (r + 1) / 2); a wave reads four
+// distinct addresses per access (one per tile row): broadcasts, no bank conflicts.  The LDS request is padded to
+// 94 KB: the kernel is latency bound and runs 4x slower when its waves share SIMDs with MFMA waves, so it must not
+// fit on a CU that holds a tile-engine workgroup (72 KB of 160).
+__device__ __forceinline__ constexpr int tri_off(int r) { return r * (r + 1) / 2; }
+constexpr int POTRF_LDS_PACKED = PB * (PB + 1) / 2;     // 8256 doubles
+constexpr int POTRF_LDS_EXCL = 11520;                   // padded: 94 KB with the vectors below
+__device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
+                                                int* __restrict__ info, double* __restrict__ S) {
     __shared__ double vec[2][PB];       // published column (factor) / row (inverse), double buffered
     __shared__ double dg[PB];           // diagonal of L
     const int tid = threadIdx.x;
@@ -132,9 +147,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
             const int r = tr * 8 + rr, c = tc * 8 + cc;
-            const double v = (c <= r) ? a[rr][cc] : 0.0;
-            S[r * PLD + c] = v;
-            a[rr][cc] = (r == c) ? 1.0 : 0.0;                                   // X = I
+            if (c <= r) S[tri_off(r) + c] = a[rr][cc];
         }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr)
@@ -142,10 +155,14 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
         for (int cc = 0; cc < 8; cc += 2) {
             const int r = tr * 8 + rr, c = tc * 8 + cc;
             f64x2 v;
-            v.x = S[r * PLD + c];      // own values, written by this thread just above
-            v.y = S[r * PLD + c + 1];
+            v.x = (c <= r) ? a[rr][cc] : 0.0;
+            v.y = (c + 1 <= r) ? a[rr][cc + 1] : 0.0;
             *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
         }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = (tr == tc && rr == cc) ? 1.0 : 0.0;   // X = I
     __syncthreads();
     // inverse: forward elimination on X = I.  Step j: row j of X (scaled by 1/d_j) is final and published;
     // rows r > j subtract L[r][j] * X[j][:].
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     xr[t] = buf[tc * 8 + t];
-                    lcol[t] = S[(tr * 8 + t) * PLD + j];
+                    lcol[t] = S[tri_off(tr * 8 + t) + j];      // entries with row < j are read but never used
                 }
                 if (tr == jt) {
 #pragma unroll
@@ -201,10 +218,25 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict
         }
 }
 
+// Alone on its CU: padded LDS request, all the registers it wants.
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag_excl(double* __restrict__ A, long ld, int p,
+                                                                   double* __restrict__ Dinv, int* __restrict__ info) {
+    __shared__ double S[POTRF_LDS_EXCL];
+    potrf_diag_body(A, ld, p, Dinv, info, S);
+}
+
+// Beside one tile-engine workgroup (72 KB LDS, 224 registers per wave): 69 KB and at most 256 registers.
+__global__ __launch_bounds__(POTRF_THREADS, 2) void k_potrf_diag_shared(double* __restrict__ A, long ld, int p,
+                                                                        double* __restrict__ Dinv, int* __restrict__ info) {
+    __shared__ double S[POTRF_LDS_PACKED];
+    potrf_diag_body(A, ld, p, Dinv, info, S);
+}
+
 // Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_panel(double* __restrict__ A, long ld, int p,
                                                              const double* __restrict__ Dinv) {
     __shared__ double lds[GEMM_LDS_DOUBLES];
+    __builtin_amdgcn_s_setprio(2);
     const int ib = p + 1 + blockIdx.x;
     double* Ap = A + (long)ib * PB * ld + (long)p * PB;
     f64x4 acc[4][4];
@@ -219,15 +251,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_panel(double* __restri
             for (int r = 0; r < 4; ++r) Ap[(long)acc_row(ta, r) * ld + acc_col(tb)] = acc[ta][tb][r];
 }
 
-// Trailing update with a group of solved panels: A[ib, jb] -= P[ib] * P[jb]^T for jb0 <= jb <= ib,
+// Trailing update with a group of solved panels: A[ib, jb] -= P[ib] * P[jb]^T,
 // P[x] = A[x, kcol0 : kcol0 + klen] (klen = 128 .. 512: several adjacent panels at once, so the
 // read-modify-write of a tile of A is paid once per group instead of once per panel).
-// grid = (number of jb, number of ib); ib = ib0 + blockIdx.y, jb = jb0 + blockIdx.x.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restrict__ A, long ld, int ib0, int jb0, int kcol0,
+// TRI: 1-D grid over the lower tiles of the square of blocks starting at b0 (ib = b0 + i, jb = b0 + j, j <= i).
+// !TRI: a rectangle of blocks, ib = b0 + blockIdx.y, jb = jb0 + blockIdx.x (every tile is computed).
+template <bool TRI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restrict__ A, long ld, int b0, int jb0, int kcol0,
                                                               int klen) {
-    const int ib = ib0 + blockIdx.y;
-    const int jb = jb0 + blockIdx.x;
-    if (jb > ib) return;
+    int ib, jb;
+    if (TRI) {
+        int i, j;
+        tri_decode(blockIdx.x, i, j);
+        ib = b0 + i;
+        jb = b0 + j;
+    } else {
+        ib = b0 + blockIdx.y;
+        jb = jb0 + blockIdx.x;
+        __builtin_amdgcn_s_setprio(2);       // the rectangular form is only used on the factorisation's critical path
+    }
     __shared__ double lds[GEMM_LDS_DOUBLES];
     const double* Pi = A + (long)ib * PB * ld + kcol0;
     const double* Pj = A + (long)jb * PB * ld + kcol0;
@@ -270,7 +312,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __r
     const int q = blockIdx.z;
     const int a0 = 2 * q * sb, b0 = a0 + sb;
     const int rows = min(sb, nb - b0);
-    const int ib = blockIdx.y, jb = blockIdx.x;
+    const int ib = blockIdx.x, jb = blockIdx.y;      // jb slow: the long tiles (small jb) are dispatched first
     if (ib >= rows) return;
     __shared__ double lds[GEMM_LDS_DOUBLES];
     f64x4 acc[4][4];
@@ -293,8 +335,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
     const int q = blockIdx.z;
     const int a0 = 2 * q * sb, b0 = a0 + sb;
     const int rows = min(sb, nb - b0);
-    const int ib = blockIdx.y, jb = blockIdx.x;
-    if (ib >= rows) return;
+    const int ib = rows - 1 - (int)blockIdx.y, jb = blockIdx.x;      // long tiles (large ib) first
+    if (ib < 0) return;
     __shared__ double lds[GEMM_LDS_DOUBLES];
     f64x4 acc[4][4];
     acc_zero(acc);
@@ -667,61 +709,76 @@ __global__ __launch_bounds__(256) void k_setup_setting(const double* __restrict_
 // in the epilogue without ever storing Kinv.  gpart[(jb*nb + kb)*GRAD_D + t] = sum_tile c_jk q_t K0_jk
 // (x2 for off-diagonal tiles); the caller zero-fills gpart.
 constexpr int GRAD_D = 16;
-__global__ __launch_bounds__(GEMM_THREADS) void k_lml_grad_tiles(const double* __restrict__ W, long ld,
-                                                                 const double* __restrict__ Xts, int n, int n_pad, int d,
-                                                                 const double* __restrict__ alpha1,
-                                                                 const double* __restrict__ params,
-                                                                 double* __restrict__ gpart, int nb) {
-    const int jb = blockIdx.y, kb = blockIdx.x;
-    if (kb > jb) return;
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double* __restrict__ W, long ld,
+                                                                    const double* __restrict__ Xts, int n, int n_pad, int d,
+                                                                    const double* __restrict__ alpha1,
+                                                                    const double* __restrict__ params,
+                                                                    double* __restrict__ gpart, int nb) {
+    int jb, kb;                    // 1-D grid over the lower tiles; jb ascending = longest contraction first
+    tri_decode(blockIdx.x, jb, kb);
     __shared__ double lds[GEMM_LDS_DOUBLES];
     f64x4 acc[4][4];
     acc_zero(acc);
     // A(j, r) = W[r][jb*128 + j], B(r, k) = W[r][kb*128 + k]; W[r][j] = 0 for r < j
     gemm_tile_128<false, false>(W + (long)jb * PB, ld, W + (long)kb * PB, ld, jb * PB, n_pad, acc, lds);
+    // The epilogue keeps nothing but the 64 accumulators live (two workgroups per CU): the tile's scaled coordinates
+    // and alpha go through LDS (the tile engine ended on a barrier), c_jk K0_jk overwrites the accumulator, and the
+    // d sums are formed one dimension at a time.
+    const int tid = threadIdx.x;
+    double* xj = lds;                        // [GRAD_D][128]
+    double* xk = lds + GRAD_D * PB;          // [GRAD_D][128]
+    double* aj = lds + 2 * GRAD_D * PB;      // [128]
+    double* ak = aj + PB;                    // [128]
+    double* red = ak + PB;                   // [4][GRAD_D]
+    for (int idx = tid; idx < d * PB; idx += GEMM_THREADS) {
+        const int t = idx >> 7, i = idx & 127;
+        xj[idx] = Xts[(long)t * n_pad + jb * PB + i];
+        xk[idx] = Xts[(long)t * n_pad + kb * PB + i];
+    }
+    if (tid < PB) aj[tid] = alpha1[jb * PB + tid];
+    else ak[tid - PB] = alpha1[kb * PB + tid - PB];
+    __syncthreads();
     const double scale_c = (double)n / params[P_YA];
-    double g[GRAD_D];
-#pragma unroll
-    for (int t = 0; t < GRAD_D; ++t) g[t] = 0.0;
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) {
-        const int k = kb * PB + acc_col(tb);
-        double xk[GRAD_D];
-#pragma unroll
-        for (int t = 0; t < GRAD_D; ++t) xk[t] = (t < d) ? Xts[(long)t * n_pad + k] : 0.0;
-        const double ak = alpha1[k];
+        const int kc = acc_col(tb);
+        const int k = kb * PB + kc;
 #pragma unroll
         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = jb * PB + acc_row(ta, r);
-                if (j < n && k < n && j != k) {
-                    double q[GRAD_D];
-                    double Dq = 0.0;
-#pragma unroll
-                    for (int t = 0; t < GRAD_D; ++t) {
-                        const double df = (t < d) ? Xts[(long)t * n_pad + j] - xk[t] : 0.0;
-                        q[t] = df * df;
-                        Dq += q[t];
-                    }
-                    const double c = (scale_c * alpha1[j] * ak - acc[ta][tb][r]) * exp(-0.5 * Dq);
-#pragma unroll
-                    for (int t = 0; t < GRAD_D; ++t) g[t] += c * q[t];
+                const int jr = acc_row(ta, r);
+                const int j = jb * PB + jr;
+                double Dq = 0.0;
+                for (int t = 0; t < d; ++t) {
+                    const double df = xj[t * PB + jr] - xk[t * PB + kc];
+                    Dq += df * df;
                 }
+                const double c = (scale_c * aj[jr] * ak[kc] - acc[ta][tb][r]) * exp(-0.5 * Dq);
+                acc[ta][tb][r] = (j < n && k < n && j != k) ? c : 0.0;
             }
     }
-    const double wgt = (jb == kb) ? 1.0 : 2.0;
-    double* red = lds;   // tile engine ended on a barrier
-    const int tid = threadIdx.x;
+    for (int t = 0; t < d; ++t) {
+        double g = 0.0;
 #pragma unroll
-    for (int t = 0; t < GRAD_D; ++t) {
-        double v = g[t];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if ((tid & 63) == 0) red[(tid >> 6) * GRAD_D + t] = v;
+        for (int tb = 0; tb < 4; ++tb) {
+            const double xkt = xk[t * PB + acc_col(tb)];
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double df = xj[t * PB + acc_row(ta, r)] - xkt;
+                    g += acc[ta][tb][r] * (df * df);
+                }
+        }
+        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
+        if ((tid & 63) == 0) red[(tid >> 6) * GRAD_D + t] = g;
     }
     __syncthreads();
+    const double wgt = (jb == kb) ? 1.0 : 2.0;
     if (tid < GRAD_D)
-        gpart[((long)jb * nb + kb) * GRAD_D + tid] = wgt * (red[tid] + red[GRAD_D + tid] + red[2 * GRAD_D + tid] + red[3 * GRAD_D + tid]);
+        gpart[((long)jb * nb + kb) * GRAD_D + tid] =
+            (tid < d) ? wgt * (red[tid] + red[GRAD_D + tid] + red[2 * GRAD_D + tid] + red[3 * GRAD_D + tid]) : 0.0;
 }
 
 // out_nll[b] = -logL (NaN when the factorisation failed), out_grad[b*d + t] = -1/2 * sum_tiles gpart / theta_t
