@@ -495,9 +495,17 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
 
 template <int D>
 void launch_sweep_t(gpbo_ctx* ctx) {
-    hipLaunchKernelGGL(k_append_sweep<D>, dim3((unsigned)((ctx->m + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->Xs,
-                       (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params, (const double*)ctx->lvec,
-                       (const double*)ctx->scal, ctx->Vres, (long)ctx->m, (int)ctx->n, ctx->sres, ctx->mu, ctx->var, ctx->kernel);
+    // two candidates per thread when every row of V starts 16-byte aligned (hipMalloc aligns the base; pitch = m)
+    if (ctx->m % 2 == 0)
+        hipLaunchKernelGGL((k_append_sweep<D, 2>), dim3((unsigned)((ctx->m / 2 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double*)ctx->Xs, (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params,
+                           (const double*)ctx->lvec, (const double*)ctx->scal, ctx->Vres, (long)ctx->m, (int)ctx->n, ctx->sres, ctx->mu,
+                           ctx->var, ctx->kernel);
+    else
+        hipLaunchKernelGGL((k_append_sweep<D, 1>), dim3((unsigned)((ctx->m + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double*)ctx->Xs, (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params,
+                           (const double*)ctx->lvec, (const double*)ctx->scal, ctx->Vres, (long)ctx->m, (int)ctx->n, ctx->sres, ctx->mu,
+                           ctx->var, ctx->kernel);
 }
 
 int append_impl(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out) {

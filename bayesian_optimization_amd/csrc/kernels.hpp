@@ -919,39 +919,85 @@ __global__ __launch_bounds__(256) void k_append_alpha(const double* __restrict__
 // The HBM-streaming sweep: per candidate j
 //   v = (k(xs_j, x_new) - sum_{k<n} l_k V[k][j]) / d_new ;  V[n][j] = v ;  s_j += v^2 ;  mu_j += v z_new ;
 //   var_j = theta1 (1 - s_j), < 1e-60 -> 0.
-template <int D>
+// A thread owns VEC adjacent candidates (VEC = 2: 16-byte loads, 1 KiB per wave instruction; needs m even) and keeps
+// eight rows of V in flight; V is read once and never again, so the loads are non-temporal.  The dot product of a
+// candidate is always eight partial sums over k mod 8, combined pairwise: the same arithmetic in both forms, so a
+// candidate's result does not depend on how the set is split over ranks.
+template <int D, int VEC>
 __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__ Xs, long m, int d_rt,
                                                       const double* __restrict__ xnew, const double* __restrict__ params,
                                                       const double* __restrict__ lvec, const double* __restrict__ scal,
                                                       double* __restrict__ V, long ldv, int n, double* __restrict__ sres,
                                                       double* __restrict__ mu, double* __restrict__ var, int kernel) {
-    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    const long j = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (j >= m) return;
     const int d = (D > 0) ? D : d_rt;
-    double Dq = 0.0;
+    double dot[VEC][8];
 #pragma unroll
-    for (int t = 0; t < ((D > 0) ? D : MAX_D); ++t)
-        if (t < d) {
-            const double df = Xs[j * d + t] * params[P_INVTHETA + t] - xnew[t];
-            Dq += df * df;
-        }
-    double dot0 = 0.0, dot1 = 0.0, dot2 = 0.0, dot3 = 0.0;
+    for (int c = 0; c < VEC; ++c)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dot[c][u] = 0.0;
+    const double* Vj = V + j;
     int k = 0;
-    for (; k + 4 <= n; k += 4) {
-        dot0 += lvec[k] * V[(long)k * ldv + j];
-        dot1 += lvec[k + 1] * V[(long)(k + 1) * ldv + j];
-        dot2 += lvec[k + 2] * V[(long)(k + 2) * ldv + j];
-        dot3 += lvec[k + 3] * V[(long)(k + 3) * ldv + j];
+    for (; k + 8 <= n; k += 8) {
+        double vv[8][VEC];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (VEC == 2) {
+                const f64x2 t = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(Vj + (long)(k + u) * ldv));
+                vv[u][0] = t.x;
+                vv[u][VEC - 1] = t.y;
+            } else {
+                vv[u][0] = __builtin_nontemporal_load(Vj + (long)(k + u) * ldv);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double l = lvec[k + u];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) dot[c][u] = fma(l, vv[u][c], dot[c][u]);
+        }
     }
-    for (; k < n; ++k) dot0 += lvec[k] * V[(long)k * ldv + j];
-    const double v = (kern_eval(Dq, kernel) - ((dot0 + dot1) + (dot2 + dot3))) / scal[A_DNEW];
-    V[(long)n * ldv + j] = v;
-    const double s = sres[j] + v * v;
-    sres[j] = s;
-    mu[j] += v * scal[A_ZNEW];
-    double vv = params[P_C0] - params[P_C1] * s;
-    if (vv < 1e-60) vv = 0.0;
-    var[j] = vv;
+    for (int u = 0; k < n; ++k, ++u) {
+        const double l = lvec[k];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const double t = Vj[(long)k * ldv + c];
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                if (w == u) dot[c][w] = fma(l, t, dot[c][w]);
+        }
+    }
+    const double dnew = scal[A_DNEW], znew = scal[A_ZNEW];
+    const double c0 = params[P_C0], c1 = params[P_C1];
+    double vout[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        double Dq = 0.0;
+#pragma unroll
+        for (int t = 0; t < ((D > 0) ? D : MAX_D); ++t)
+            if (t < d) {
+                const double df = Xs[(j + c) * d + t] * params[P_INVTHETA + t] - xnew[t];
+                Dq += df * df;
+            }
+        const double sum = ((dot[c][0] + dot[c][1]) + (dot[c][2] + dot[c][3])) + ((dot[c][4] + dot[c][5]) + (dot[c][6] + dot[c][7]));
+        const double v = (kern_eval(Dq, kernel) - sum) / dnew;
+        vout[c] = v;
+        const double s = sres[j + c] + v * v;
+        sres[j + c] = s;
+        mu[j + c] += v * znew;
+        double vr = c0 - c1 * s;
+        if (vr < 1e-60) vr = 0.0;
+        var[j + c] = vr;
+    }
+    if (VEC == 2) {
+        f64x2 t;
+        t.x = vout[0];
+        t.y = vout[VEC - 1];
+        *reinterpret_cast<f64x2*>(V + (long)n * ldv + j) = t;
+    } else {
+        V[(long)n * ldv + j] = vout[0];
+    }
 }
 
 
