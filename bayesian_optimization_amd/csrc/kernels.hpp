@@ -1054,6 +1054,32 @@ __global__ __launch_bounds__(256) void k_kernel_from_absdiff(const double* __res
     K[e] = kern_eval(D, kernel);
 }
 
+// out[0] = min, out[1] = max of diag(L), rows < n.  One workgroup.
+__global__ __launch_bounds__(256) void k_diag_minmax(const double* __restrict__ L, long ld, int n, double* __restrict__ out) {
+    __shared__ double lo[256], hi[256];
+    const int tid = threadIdx.x;
+    double a = INFINITY, b = -INFINITY;
+    for (int i = tid; i < n; i += 256) {
+        const double v = L[(long)i * ld + i];
+        a = fmin(a, v);
+        b = fmax(b, v);
+    }
+    lo[tid] = a;
+    hi[tid] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            lo[tid] = fmin(lo[tid], lo[tid + o]);
+            hi[tid] = fmax(hi[tid], hi[tid + o]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = lo[0];
+        out[1] = hi[0];
+    }
+}
+
 __global__ void k_set_scalar(double* dst, double v) { *dst = v; }
 __global__ void k_copy_scalar(double* dst, const double* src) { *dst = *src; }
 

@@ -199,6 +199,12 @@ class GP:
         self._check(self._lib.gpbo_model_scalars(self._h, C.byref(t1), C.byref(nll), C.byref(ym), C.byref(n)))
         self.theta1, self.nll, self.y_max, self.n = t1.value, nll.value, ym.value, int(n.value)
 
+    def cond_estimate(self):
+        """(max diag L / min diag L)^2 of the factor the posterior uses: a lower bound of cond_2 of the factored matrix."""
+        c = C.c_double()
+        self._check(self._lib.gpbo_cond_estimate(self._h, C.byref(c)))
+        return c.value
+
     def factor(self, want_L=True, want_alpha=True):
         Lm = np.empty((self.n, self.n)) if want_L else None
         al = np.empty(self.n) if want_alpha else None

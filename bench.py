@@ -199,6 +199,9 @@ def main():
     ap.add_argument('--replicas', action='store_true', help='cfg4 with several GPUs: independent loops instead of one sharded loop')
     ap.add_argument('--settings', type=int, default=0, help='cfg5: settings per GPU (default 256 / gpus)')
     a = ap.parse_args()
+    if os.environ.get('GPBO_STALL_DUMP'):      # diagnosis: dump every thread's Python stack if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['GPBO_STALL_DUMP']), exit=False)
     if a.config in ('cfg4', 'cfg5'):
         return secondary(a)
 
@@ -225,6 +228,7 @@ def main():
     if rank == 0:
         gp.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
         fit_tm = gp.timings()
+        cond_est = gp.cond_estimate()
     gdist.broadcast_model(gp, 0)
     Xs = synth.candidates(cfg, lo, hi)
     gp.set_candidates(Xs)
@@ -287,7 +291,8 @@ def main():
             nchol = max(fit_tm['chol_count'], 1)
             out['fit'] = {'total_ms': fit_tm['fit_total_ms'], 'cholesky_ms_each': fit_tm['chol_ms'] / nchol,
                           'cholesky_gflops': (n ** 3 / 3.0) / (fit_tm['chol_ms'] / nchol * 1e-3) / 1e9,
-                          'inverse_ms': fit_tm['inverse_ms'], 'trsv_ms': fit_tm['trsv_ms'], 'kbuild_ms': fit_tm['kbuild_ms']}
+                          'inverse_ms': fit_tm['inverse_ms'], 'trsv_ms': fit_tm['trsv_ms'], 'kbuild_ms': fit_tm['kbuild_ms'],
+                          'cond_estimate': cond_est}
         if world == 1 and not a.no_cpu_baseline:
             ns = 16384 if n <= 8192 else 2048
             base, st, (mu_o, var_o) = cpu_baseline(cfg, X, y, theta, Xs[:ns])

@@ -173,6 +173,11 @@ int gpbo_last_timings(gpbo_ctx* ctx, gpbo_timings* out);
 /* Scalars of the current model: theta1 (BayesOpt_v4.ipynb:144), -logL (:164), max(yTrain), n.  Any may be NULL. */
 int gpbo_model_scalars(gpbo_ctx* ctx, double* theta1_out, double* nll_out, double* y_max_out, int64_t* n_out);
 
+/* Conditioning diagnostic of the factored matrix (the one np.linalg.cholesky receives at BayesOpt_v4.ipynb:142, or
+ * :147 for the v4 variant): (max diag L / min diag L)^2, a lower bound of its 2-norm condition number.  Needs the
+ * factor on this context (the rank that called gpbo_fit). */
+int gpbo_cond_estimate(gpbo_ctx* ctx, double* cond_out);
+
 /* Multi-GPU: rank 0 fits, gpbo_state_describe() exposes the device buffers that the
  * other ranks need; they call gpbo_state_alloc() with the same shape, receive the
  * bytes into the described buffers (RCCL broadcast), then gpbo_state_commit(). */

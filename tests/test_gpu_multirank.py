@@ -13,16 +13,26 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+def _run(cmd, env, tag):
+    """Runs the launcher with stdout/stderr going to files (kept for diagnosis if the ranks stall), returns stdout."""
+    logdir = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(logdir, exist_ok=True)
+    po, pe = os.path.join(logdir, tag + '.out'), os.path.join(logdir, tag + '.err')
+    with open(po, 'w') as fo, open(pe, 'w') as fe:
+        proc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=fo, stderr=fe, timeout=float(os.environ.get('GPBO_TEST_TIMEOUT', '150')))
+    assert proc.returncode == 0, open(pe).read()[-2000:]
+    return open(po).read()
+
+
 def test_two_rank_sweep_equals_single_process(gp0):
     from bayesian_optimization_amd import synth
     m_per = 65536
-    env = dict(os.environ, GPBO_DIST_BACKEND='gloo', GPBO_FORCE_DEVICE='0', MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, GPBO_DIST_BACKEND='gloo', GPBO_FORCE_DEVICE='0', MASTER_ADDR='127.0.0.1', GPBO_STALL_DUMP='60')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
            '--candidates', str(m_per)]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    out = _run(cmd, env, 'two_rank_sweep')
+    line = [ln for ln in out.splitlines() if ln.startswith('{')][-1]
     res = json.loads(line)
     assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['candidates_per_gpu'] == m_per
     cfg = synth.CONFIGS['cfg2']
@@ -41,13 +51,12 @@ def test_two_rank_sharded_loop_picks_the_same_points(gp0):
     import bayesian_optimization_amd as bo
     from bayesian_optimization_amd import synth, dist as gdist
     side, iters, d, n0 = 16, 12, 4, 16
-    env = dict(os.environ, GPBO_DIST_BACKEND='gloo', GPBO_FORCE_DEVICE='0', MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, GPBO_DIST_BACKEND='gloo', GPBO_FORCE_DEVICE='0', MASTER_ADDR='127.0.0.1', GPBO_STALL_DUMP='60')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29543', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', 'cfg4', '--side', str(side),
            '--iters', str(iters), '--warmup', '0']
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    out = _run(cmd, env, 'two_rank_loop')
+    res = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
     assert res['n_gpus'] == 2 and res['scaling'] == 'strong'
     g1 = (np.arange(side) + 0.5) / side
     grid = np.stack(np.meshgrid(g1, g1, g1, g1, indexing='ij'), -1).reshape(-1, d)

@@ -334,3 +334,14 @@ def test_config3_shape_identities(gp0):
     gp0.posterior()
     mu2, var2 = gp0.read()
     assert np.array_equal(mu1, mu2) and np.array_equal(var1, var2)
+
+
+def test_cond_estimate_matches_the_factor_diagonal(gp0):
+    g = golden('g3_d4_n64_s1e-2') if 'g3_d4_n64_s1e-2' in golden_names('g3') else golden(golden_names('g3')[0])
+    gp0.fit(g['xTrain'], g['yTrain'], g['theta'], float(g['sigmaY']))
+    Lm, _ = gp0.factor()
+    dg = np.diag(Lm)
+    est = gp0.cond_estimate()
+    assert abs(est - (dg.max() / dg.min()) ** 2) <= 1e-12 * est
+    K = Lm @ Lm.T
+    assert est <= np.linalg.cond(K) * (1 + 1e-8)          # a lower bound of the 2-norm condition number
