@@ -1249,6 +1249,67 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     const int nb = (int)(n_pad / PB);
     const int ntiles = nb * nb;
 
+    // Up to 128 points: one workgroup evaluates one setting from start to end (k_lml_small), one launch for all B.
+    bool small = (n_pad == PB && d <= GRAD_D);
+    if (const char* e = getenv("GPBO_LML_SMALL")) small = small && atoi(e) != 0;
+    if (small) {
+        double *Xraw = nullptr, *yd = nullptr, *thd = nullptr, *sgd = nullptr, *onll = nullptr, *ograd = nullptr;
+        int* infos = nullptr;
+        auto cleanup = [&]() {
+            for (void* p : {(void*)Xraw, (void*)yd, (void*)thd, (void*)sgd, (void*)onll, (void*)ograd, (void*)infos})
+                if (p) hipFree(p);
+        };
+#define SCHK(expr)                                                        \
+    do {                                                                  \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess) {                                           \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_); \
+            cleanup();                                                    \
+            return GPBO_ERR_HIP;                                          \
+        }                                                                 \
+    } while (0)
+        std::vector<double> xr((size_t)d * PB, 0.0), yp(PB, 0.0);
+        for (int t = 0; t < d; ++t)
+            for (int64_t i = 0; i < n; ++i) xr[(size_t)t * PB + i] = X[i * d + t];
+        for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
+        SCHK(hipMalloc((void**)&Xraw, xr.size() * 8));
+        SCHK(hipMalloc((void**)&yd, PB * 8));
+        SCHK(hipMalloc((void**)&thd, (size_t)B * d * 8));
+        SCHK(hipMalloc((void**)&sgd, (size_t)B * 8));
+        SCHK(hipMalloc((void**)&onll, (size_t)B * 8));
+        SCHK(hipMalloc((void**)&ograd, (size_t)B * d * 8));
+        SCHK(hipMalloc((void**)&infos, (size_t)B * sizeof(int)));
+        SCHK(hipMemcpyAsync(Xraw, xr.data(), xr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        SCHK(hipMemcpyAsync(yd, yp.data(), PB * 8, hipMemcpyHostToDevice, ctx->stream));
+        SCHK(hipMemcpyAsync(thd, thetas, (size_t)B * d * 8, hipMemcpyHostToDevice, ctx->stream));
+        SCHK(hipMemcpyAsync(sgd, sigmas, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_lml_small, dim3((unsigned)B), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)Xraw, (int)PB,
+                           (const double*)yd, (int)n, (int)d, (const double*)thd, (const double*)sgd, (int)kernel, grad_out ? 1 : 0,
+                           onll, ograd, infos);
+        SCHK(hipGetLastError());
+        std::vector<int> hinfo(B);
+        SCHK(hipMemcpyAsync(nll_out, onll, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (grad_out) SCHK(hipMemcpyAsync(grad_out, ograd, (size_t)B * d * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SCHK(hipMemcpyAsync(hinfo.data(), infos, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SCHK(hipStreamSynchronize(ctx->stream));
+#undef SCHK
+        ctx->tm.fit_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ctx->tm.chol_count = B;
+        ctx->tm.kbuild_ms = ctx->tm.chol_ms = ctx->tm.trsv_ms = ctx->tm.inverse_ms = 0;
+        for (int b = 0; b < B; ++b) {
+            const bool bad = hinfo[b] != 0 || !std::isfinite(nll_out[b]);
+            if (status_out) status_out[b] = bad ? GPBO_ERR_NOT_PD : GPBO_OK;
+            if (bad) {
+                nll_out[b] = NAN;
+                if (grad_out)
+                    for (int t = 0; t < d; ++t) grad_out[(size_t)b * d + t] = NAN;
+            }
+        }
+        cleanup();
+        return GPBO_OK;
+    }
+
     // The settings are independent.  Each lane = a context of its own (work matrices + stream); settings are dealt
     // round-robin over the lanes so that the latency-bound parts of one factorisation (diagonal blocks, panel
     // solves, triangular solves) overlap the MFMA-bound updates of the others.  Lane 0 is the caller's context.

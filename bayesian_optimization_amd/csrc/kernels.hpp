@@ -83,29 +83,18 @@ constexpr int POTRF_THREADS = 256;
 __device__ __forceinline__ constexpr int tri_off(int r) { return r * (r + 1) / 2; }
 constexpr int POTRF_LDS_PACKED = PB * (PB + 1) / 2;     // 8256 doubles
 constexpr int POTRF_LDS_EXCL = 11520;                   // padded: 94 KB with the vectors below
-__device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
-                                                int* __restrict__ info, double* __restrict__ S) {
-    __shared__ double vec[2][PB];       // published column (factor) / row (inverse), double buffered
-    __shared__ double dg[PB];           // diagonal of L
+// Factor phase on register tiles.  vec: [2][PB] LDS, dg: [PB] LDS (receives diag L).  Returns the first failing
+// column (pivot <= 0 or NaN) or -1.  All 256 threads must call it; it ends without a barrier after the last step.
+__device__ __forceinline__ int potrf_factor_regs(double (&a)[8][8], double* __restrict__ vec, double* __restrict__ dg) {
     const int tid = threadIdx.x;
     const int tr = tid >> 4, tc = tid & 15;
     const bool lower = tr >= tc;
-    double* blk = A + (long)p * PB * ld + (long)p * PB;
-    double a[8][8];
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; cc += 2) {
-            const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)(tr * 8 + rr) * ld + tc * 8 + cc);
-            a[rr][cc] = v.x;
-            a[rr][cc + 1] = v.y;
-        }
     int fail = -1;
     for (int jt = 0; jt < 16; ++jt) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = jt * 8 + jj;
-            double* buf = vec[j & 1];
+            double* buf = vec + (j & 1) * PB;
             if (tc == jt && lower) {
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) buf[tr * 8 + rr] = a[rr][jj];
@@ -140,37 +129,26 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
             if (tid == 0) dg[j] = d;
         }
     }
-    if (tid == 0 && fail >= 0) atomicCAS(info, 0, p * PB + fail + 1);
-    // L -> global (zeros above the diagonal) and -> LDS for the inverse
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            const int r = tr * 8 + rr, c = tc * 8 + cc;
-            if (c <= r) S[tri_off(r) + c] = a[rr][cc];
-        }
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; cc += 2) {
-            const int r = tr * 8 + rr, c = tc * 8 + cc;
-            f64x2 v;
-            v.x = (c <= r) ? a[rr][cc] : 0.0;
-            v.y = (c + 1 <= r) ? a[rr][cc + 1] : 0.0;
-            *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
-        }
+    return fail;
+}
+
+// Inverse phase: forward elimination on X = I held in the register tiles (a is overwritten), L read from the packed
+// LDS copy S, diag L from dg.  Step j: row j of X (scaled by 1/d_j) is final and published; rows r > j subtract
+// L[r][j] * X[j][:].  The caller has written S and dg and passed a barrier.
+__device__ __forceinline__ void potrf_inverse_regs(double (&a)[8][8], const double* __restrict__ S, double* __restrict__ vec,
+                                                   const double* __restrict__ dg) {
+    const int tid = threadIdx.x;
+    const int tr = tid >> 4, tc = tid & 15;
+    const bool lower = tr >= tc;
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) a[rr][cc] = (tr == tc && rr == cc) ? 1.0 : 0.0;   // X = I
-    __syncthreads();
-    // inverse: forward elimination on X = I.  Step j: row j of X (scaled by 1/d_j) is final and published;
-    // rows r > j subtract L[r][j] * X[j][:].
     for (int jt = 0; jt < 16; ++jt) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = jt * 8 + jj;
-            double* buf = vec[j & 1];
+            double* buf = vec + (j & 1) * PB;
             if (tr == jt && lower) {
                 const double rd = 1.0 / dg[j];
 #pragma unroll
@@ -205,6 +183,46 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
             }
         }
     }
+}
+
+__device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
+                                                int* __restrict__ info, double* __restrict__ S) {
+    __shared__ double vec[2 * PB];      // published column (factor) / row (inverse), double buffered
+    __shared__ double dg[PB];           // diagonal of L
+    const int tid = threadIdx.x;
+    const int tr = tid >> 4, tc = tid & 15;
+    double* blk = A + (long)p * PB * ld + (long)p * PB;
+    double a[8][8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; cc += 2) {
+            const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)(tr * 8 + rr) * ld + tc * 8 + cc);
+            a[rr][cc] = v.x;
+            a[rr][cc + 1] = v.y;
+        }
+    const int fail = potrf_factor_regs(a, vec, dg);
+    if (tid == 0 && fail >= 0) atomicCAS(info, 0, p * PB + fail + 1);
+    // L -> global (zeros above the diagonal) and -> LDS for the inverse
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int r = tr * 8 + rr, c = tc * 8 + cc;
+            if (c <= r) S[tri_off(r) + c] = a[rr][cc];
+        }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; cc += 2) {
+            const int r = tr * 8 + rr, c = tc * 8 + cc;
+            f64x2 v;
+            v.x = (c <= r) ? a[rr][cc] : 0.0;
+            v.y = (c + 1 <= r) ? a[rr][cc + 1] : 0.0;
+            *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
+        }
+    __syncthreads();
+    potrf_inverse_regs(a, S, vec, dg);
     double* dinv = Dinv + (long)p * PB * PB;
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr)
@@ -779,6 +797,174 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
     if (tid < GRAD_D)
         gpart[((long)jb * nb + kb) * GRAD_D + tid] =
             (tid < d) ? wgt * (red[tid] + red[GRAD_D + tid] + red[2 * GRAD_D + tid] + red[3 * GRAD_D + tid]) : 0.0;
+}
+
+// Whole -logL (+ gradient) evaluation of ONE hyper-parameter setting in ONE workgroup, for n <= 128: covariance
+// tiles built in registers, factor and inverse as in the diagonal-block kernel, z = W y, alpha = W^T z, the
+// scalars, then Kinv = W^T W tile by tile out of LDS and the gradient sums.  grid = number of settings: a
+// multi-start fit on ~100 points is one launch instead of ten launches per setting.
+//   nll = n/2 (log 2pi + 1) + n/2 log(theta1) + sum log diag L,  theta1 = y.alpha / n       (mlefcn)
+//   g_t = -1/(2 theta_t) sum_{j != k} (n a_j a_k / (y.a) - Kinv_jk) q_t K0_jk                  (jacmlefun, RBF)
+// LDS: W with pitch 129 (the packed copy of L lives in the same space while the inverse runs), scaled inputs, vectors.
+constexpr int SMALL_WP = PB + 1;
+constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 2 * PB + 6 * PB + 4 * GRAD_D + 8;
+__global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __restrict__ Xraw, int xpitch,
+                                                             const double* __restrict__ y, int n, int d,
+                                                             const double* __restrict__ thetas,
+                                                             const double* __restrict__ sigmas, int kernel, int want_grad,
+                                                             double* __restrict__ out_nll, double* __restrict__ out_grad,
+                                                             int* __restrict__ out_info) {
+    __shared__ double lds[SMALL_LDS_DOUBLES];
+    double* Wl = lds;                         // [128][129]; first the packed L
+    double* xs = Wl + PB * SMALL_WP;          // [GRAD_D][128] inputs / theta
+    double* vec = xs + GRAD_D * PB;           // [2][128]
+    double* dg = vec + 2 * PB;                // [128]
+    double* yv = dg + PB;
+    double* zv = yv + PB;
+    double* al = zv + PB;
+    double* r1 = al + PB;                     // [128] reduction scratch: y_i alpha_i
+    double* r2 = r1 + PB;                     // [128] reduction scratch: log diag L
+    double* red = r2 + PB;                    // [4][GRAD_D]
+    double* sc = red + 4 * GRAD_D;            // [0] y.alpha  [1] sum log diag L
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int tr = tid >> 4, tc = tid & 15;
+    const double* th = thetas + (long)b * d;
+    const double sg = sigmas[b];
+    const double eps = (sg == 0.0) ? 1e-15 * (double)n : sg * sg;
+    for (int idx = tid; idx < d * PB; idx += POTRF_THREADS) {
+        const int t = idx >> 7, i = idx & 127;
+        xs[idx] = (i < n) ? Xraw[(long)t * xpitch + i] * (1.0 / th[t]) : 0.0;
+    }
+    if (tid < PB) yv[tid] = (tid < n) ? y[tid] : 0.0;
+    __syncthreads();
+    double a[8][8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int r = tr * 8 + rr, c = tc * 8 + cc;
+            double v = 0.0;
+            if (r == c) {
+                v = (r < n) ? 1.0 + eps : 1.0;
+            } else if (r < n && c < n && c < r) {
+                double D = 0.0;
+                for (int t = 0; t < d; ++t) {
+                    const double df = xs[t * PB + r] - xs[t * PB + c];
+                    D += df * df;
+                }
+                v = kern_eval(D, kernel);
+            }
+            a[rr][cc] = v;
+        }
+    const int fail = potrf_factor_regs(a, vec, dg);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int r = tr * 8 + rr, c = tc * 8 + cc;
+            if (c <= r) Wl[tri_off(r) + c] = a[rr][cc];
+        }
+    __syncthreads();
+    potrf_inverse_regs(a, Wl, vec, dg);
+    __syncthreads();                           // every read of the packed L is done
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int r = tr * 8 + rr, c = tc * 8 + cc;
+            Wl[r * SMALL_WP + c] = (c <= r) ? a[rr][cc] : 0.0;
+        }
+    __syncthreads();
+    if (tid < PB) {                            // z = W y (row tid)
+        double z = 0.0;
+        for (int c = 0; c <= tid; ++c) z = fma(Wl[tid * SMALL_WP + c], yv[c], z);
+        zv[tid] = z;
+    }
+    __syncthreads();
+    if (tid < PB) {                            // alpha = W^T z (column tid)
+        double s = 0.0;
+        for (int r = tid; r < PB; ++r) s = fma(Wl[r * SMALL_WP + tid], zv[r], s);
+        al[tid] = s;
+        r1[tid] = yv[tid] * s;
+        r2[tid] = (tid < n) ? log(dg[tid]) : 0.0;
+    }
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (tid < o) {
+            r1[tid] += r1[tid + o];
+            r2[tid] += r2[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        sc[0] = r1[0];
+        sc[1] = r2[0];
+    }
+    __syncthreads();
+    const double ya = sc[0], sumlog = sc[1];
+    const double theta1 = ya / n;
+    const bool bad = fail >= 0;
+    if (tid == 0) {
+        const double nll = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(theta1) + sumlog;
+        out_nll[b] = bad ? NAN : nll;
+        out_info[b] = bad ? fail + 1 : 0;
+    }
+    if (!want_grad) return;
+    // Kinv tile (tr, tc), tr >= tc: sum over r >= 8 tr of W[r][8 tr + rr] W[r][8 tc + cc] (W is zero above its diagonal)
+    const bool lower = tr >= tc;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = 0.0;
+    if (lower) {
+        for (int r = tr * 8; r < PB; ++r) {
+            double wj[8], wk[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                wj[t] = Wl[r * SMALL_WP + tr * 8 + t];
+                wk[t] = Wl[r * SMALL_WP + tc * 8 + t];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) a[rr][cc] = fma(wj[rr], wk[cc], a[rr][cc]);
+        }
+        const double scale_c = (double)n / ya;
+        const double wgt = (tr == tc) ? 1.0 : 2.0;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                const int j = tr * 8 + rr, k = tc * 8 + cc;
+                double D = 0.0;
+                for (int t = 0; t < d; ++t) {
+                    const double df = xs[t * PB + j] - xs[t * PB + k];
+                    D += df * df;
+                }
+                const double c = wgt * (scale_c * al[j] * al[k] - a[rr][cc]) * exp(-0.5 * D);
+                a[rr][cc] = (j < n && k < n && j != k) ? c : 0.0;
+            }
+    }
+    for (int t = 0; t < d; ++t) {
+        double g = 0.0;
+        if (lower) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    const double df = xs[t * PB + tr * 8 + rr] - xs[t * PB + tc * 8 + cc];
+                    g = fma(a[rr][cc], df * df, g);
+                }
+        }
+        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
+        if ((tid & 63) == 0) red[(tid >> 6) * GRAD_D + t] = g;
+    }
+    __syncthreads();
+    if (tid < d) {
+        const double sum = (red[tid] + red[GRAD_D + tid]) + (red[2 * GRAD_D + tid] + red[3 * GRAD_D + tid]);
+        out_grad[(long)b * d + tid] = bad ? NAN : -0.5 * sum * (1.0 / th[tid]);
+    }
 }
 
 // out_nll[b] = -logL (NaN when the factorisation failed), out_grad[b*d + t] = -1/2 * sum_tiles gpart / theta_t

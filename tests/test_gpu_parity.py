@@ -345,3 +345,43 @@ def test_cond_estimate_matches_the_factor_diagonal(gp0):
     assert abs(est - (dg.max() / dg.min()) ** 2) <= 1e-12 * est
     K = Lm @ Lm.T
     assert est <= np.linalg.cond(K) * (1 + 1e-8)          # a lower bound of the 2-norm condition number
+
+
+def test_small_n_fused_likelihood_equals_the_general_path(gp0):
+    """n <= 128 runs one workgroup per setting; the same settings through the general (multi-launch) path and
+    through the oracle must agree, including a setting whose factorisation fails."""
+    import subprocess, sys, json, os
+    from conftest import ROOT
+    n, d = 94, 3
+    X = o.splitmix64_uniform(91, n * d).reshape(n, d)
+    y = np.sin(4 * X[:, 0]) + X[:, 1] ** 2 - 0.5 * X[:, 2]
+    rng = np.random.default_rng(5)
+    B = 40
+    thetas = rng.uniform(0.08, 0.9, size=(B, d))
+    sigmas = np.where(np.arange(B) % 3 == 0, 0.0, rng.uniform(1e-3, 0.3, size=B))
+    nll, grad, stat = gp0.lml_batch(X, y, thetas, sigmas, grad=True)
+    ok = 0
+    for b in range(B):
+        ref = o.mlefcn(X, y, thetas[b], sigmas[b])
+        gref = o.mle_grad(X, y, thetas[b], sigmas[b])
+        cond_ok = sigmas[b] > 0 or thetas[b].max() <= 0.2          # sigma = 0 with long length scales: numerically singular
+        if stat[b] == 0 and cond_ok:
+            assert abs(nll[b] - ref) <= 1e-8 * max(1.0, abs(ref)), (b, nll[b], ref)
+            assert np.max(np.abs(grad[b] - gref)) <= 1e-6 * max(1.0, np.max(np.abs(gref))), (b, grad[b], gref)
+            ok += 1
+        assert (stat[b] == 1) == bool(np.isnan(nll[b]))
+    assert ok >= B // 2
+    # the general path, in a child process (the switch is read from the environment)
+    code = ('import json,sys,numpy as np; sys.path.insert(0, %r); from bayesian_optimization_amd import GP; '
+            'z=np.load(sys.argv[1]); g=GP(0); r=g.lml_batch(z["X"],z["y"],z["th"],z["sg"],grad=True); '
+            'np.savez(sys.argv[2], nll=r[0], grad=r[1], stat=r[2])' % ROOT)
+    tmp = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(tmp, exist_ok=True)
+    fin, fout = os.path.join(tmp, 'small_in.npz'), os.path.join(tmp, 'small_out.npz')
+    np.savez(fin, X=X, y=y, th=thetas, sg=sigmas)
+    subprocess.run([sys.executable, '-c', code, fin, fout], env=dict(os.environ, GPBO_LML_SMALL='0'), check=True, timeout=120)
+    z = np.load(fout)
+    good = (stat == 0) & (z['stat'] == 0) & ((sigmas > 0) | (thetas.max(1) <= 0.2))
+    assert good.sum() >= B // 2
+    assert np.max(np.abs(nll[good] - z['nll'][good]) / np.maximum(1.0, np.abs(nll[good]))) <= 1e-9
+    assert np.max(np.abs(grad[good] - z['grad'][good])) <= 1e-7 * max(1.0, np.max(np.abs(grad[good])))
