@@ -86,3 +86,35 @@ def test_sharded_lml_single_process_equals_lml_batch(gp0):
     b = gdist.sharded_lml(gp0, X, y, th, sg, grad=True)
     for p, q in zip(a, b):
         assert np.array_equal(p, q)
+
+
+def test_rccl_code_path_with_a_single_rank():
+    """One rank over the nccl (= RCCL) backend: the device-tensor exchanges of the sharded sweep (in-place broadcast of the
+    model buffers through zero-copy views, all-reduce of max(Mu), all-gather of the argmax pairs) run through RCCL itself."""
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from bayesian_optimization_amd import GP, synth, dist as gdist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+gdist._is_dist = lambda: True                      # world_size 1 normally short-circuits the exchanges
+cfg = dict(synth.CONFIGS['cfg2']); cfg['n'] = 512
+X, y, theta = synth.training_set(cfg)
+gp = GP(0); gp.fit(X, y, theta, cfg['sigmaY'])
+Xs = synth.candidates(cfg, 0, 4096)
+gp.set_candidates(Xs); mu0 = gp.posterior(); i0, b0 = gp.acquire(0, cfg['kappa'])
+gdist.broadcast_model(gp, 0)                       # broadcasts W, alpha, Xts, params in place over RCCL
+gidx, gbest, mu_max = gdist.ShardedSweep(gp, offset=0).step(0, cfg['kappa'])
+assert (gidx, gbest, mu_max) == (i0, b0, mu0), ((gidx, gbest, mu_max), (i0, b0, mu0))
+assert np.array_equal(gdist.allreduce_sum(np.arange(5.0), 0), np.arange(5.0))
+dist.destroy_process_group()
+print('RCCL_OK')
+'''
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29549')
+    logdir = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(logdir, exist_ok=True)
+    with open(os.path.join(logdir, 'rccl_single.out'), 'w') as fo, open(os.path.join(logdir, 'rccl_single.err'), 'w') as fe:
+        proc = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, stdout=fo, stderr=fe, timeout=150)
+    err = open(os.path.join(logdir, 'rccl_single.err')).read()
+    assert proc.returncode == 0, err[-2000:]
+    assert 'RCCL_OK' in open(os.path.join(logdir, 'rccl_single.out')).read()
