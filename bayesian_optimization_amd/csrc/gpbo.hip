@@ -1238,7 +1238,6 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     if (!X || !y || !thetas || !sigmas || !nll_out) BADARG("lml_batch: null input");
     if (n <= 0 || d <= 0 || d > MAX_D || B <= 0) BADARG("lml_batch: need n >= 1, 1 <= d <= 32, B >= 1");
     if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN52) BADARG("lml_batch: unknown kernel");
-    if (grad_out && kernel != GPBO_KERNEL_RBF) BADARG("lml_batch: the analytic gradient exists for the RBF kernel only");
     if (grad_out && d > GRAD_D) BADARG("lml_batch: gradient supports d <= 16");
     for (int64_t i = 0; i < (int64_t)B * d; ++i)
         if (!(thetas[i] != 0.0) || !std::isfinite(thetas[i])) BADARG("lml_batch: theta entries must be finite and non-zero");
@@ -1413,7 +1412,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
                     hipMemsetAsync(gpart[b % lanes], 0, (size_t)ntiles * GRAD_D * 8, c->stream);
                     hipLaunchKernelGGL(k_lml_grad_tiles, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(GEMM_THREADS), 0, c->stream, (const double*)c->bufW,
                                        (long)n_pad, (const double*)c->Xts, (int)n, (int)n_pad, (int)d, (const double*)c->alpha1,
-                                       (const double*)c->params, gpart[b % lanes], nb);
+                                       (const double*)c->params, gpart[b % lanes], nb, (int)kernel);
                 }
             }
         }

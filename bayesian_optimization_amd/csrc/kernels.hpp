@@ -36,6 +36,13 @@ __device__ __forceinline__ double kern_eval(double D, int kernel) {
     return (1.0 + s5r + (5.0 / 3.0) * D) * exp(-s5r);
 }
 
+// -2 dk/d(D) as a function of the scaled squared distance D: the factor F in dK/dtheta_t = F q_t / theta_t.
+__device__ __forceinline__ double kern_dfac(double D, int kernel) {
+    if (kernel == 0) return exp(-0.5 * D);
+    const double s5r = 2.23606797749978969641 * sqrt(D);
+    return (5.0 / 3.0) * (1.0 + s5r) * exp(-s5r);
+}
+
 // ---------------------------------------------------------------------------------------
 // K(X,X): full symmetric n_pad x n_pad matrix, scale*k(D) + eps on the diagonal, identity pad.
 // Xts is [d][n_pad] = X / theta.  scale_ptr == nullptr -> 1.
@@ -720,8 +727,8 @@ __global__ __launch_bounds__(256) void k_setup_setting(const double* __restrict_
     if (i == 0) params[P_INVTHETA + t] = it;
 }
 
-// Gradient of -logL w.r.t. theta (RBF):  g_t = -1/2 sum_{j,k} c_jk dK_t[j][k],
-//   c_jk = n a_j a_k / (y.a) - Kinv_jk,  Kinv = W^T W,  dK_t[j][k] = q_t K0_jk / theta_t,
+// Gradient of -logL w.r.t. theta:  g_t = -1/2 sum_{j,k} c_jk dK_t[j][k],
+//   c_jk = n a_j a_k / (y.a) - Kinv_jk,  Kinv = W^T W,  dK_t[j][k] = q_t F_jk / theta_t  (F = K0 for RBF, see kern_dfac),
 //   q_t = ((x_jt - x_kt)/theta_t)^2.
 // One workgroup = one lower tile (jb >= kb) of Kinv on the MFMA tile engine, reduced against dK_t
 // in the epilogue without ever storing Kinv.  gpart[(jb*nb + kb)*GRAD_D + t] = sum_tile c_jk q_t K0_jk
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
                                                                     const double* __restrict__ Xts, int n, int n_pad, int d,
                                                                     const double* __restrict__ alpha1,
                                                                     const double* __restrict__ params,
-                                                                    double* __restrict__ gpart, int nb) {
+                                                                    double* __restrict__ gpart, int nb, int kernel) {
     int jb, kb;                    // 1-D grid over the lower tiles; jb ascending = longest contraction first
     tri_decode(blockIdx.x, jb, kb);
     __shared__ double lds[GEMM_LDS_DOUBLES];
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
                     const double df = xj[t * PB + jr] - xk[t * PB + kc];
                     Dq += df * df;
                 }
-                const double c = (scale_c * aj[jr] * ak[kc] - acc[ta][tb][r]) * exp(-0.5 * Dq);
+                const double c = (scale_c * aj[jr] * ak[kc] - acc[ta][tb][r]) * kern_dfac(Dq, kernel);
                 acc[ta][tb][r] = (j < n && k < n && j != k) ? c : 0.0;
             }
     }
@@ -804,7 +811,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
 // scalars, then Kinv = W^T W tile by tile out of LDS and the gradient sums.  grid = number of settings: a
 // multi-start fit on ~100 points is one launch instead of ten launches per setting.
 //   nll = n/2 (log 2pi + 1) + n/2 log(theta1) + sum log diag L,  theta1 = y.alpha / n       (mlefcn)
-//   g_t = -1/(2 theta_t) sum_{j != k} (n a_j a_k / (y.a) - Kinv_jk) q_t K0_jk                  (jacmlefun, RBF)
+//   g_t = -1/(2 theta_t) sum_{j != k} (n a_j a_k / (y.a) - Kinv_jk) q_t F_jk   (jacmlefun; F = K0 for RBF, kern_dfac)
 // LDS: W with pitch 129 (the packed copy of L lives in the same space while the inverse runs), scaled inputs, vectors.
 constexpr int SMALL_WP = PB + 1;
 constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 2 * PB + 6 * PB + 4 * GRAD_D + 8;
@@ -942,7 +949,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
                     const double df = xs[t * PB + j] - xs[t * PB + k];
                     D += df * df;
                 }
-                const double c = wgt * (scale_c * al[j] * al[k] - a[rr][cc]) * exp(-0.5 * D);
+                const double c = wgt * (scale_c * al[j] * al[k] - a[rr][cc]) * kern_dfac(D, kernel);
                 a[rr][cc] = (j < n && k < n && j != k) ? c : 0.0;
             }
     }

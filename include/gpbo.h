@@ -157,7 +157,7 @@ int gpbo_kernel_from_distances(gpbo_ctx* ctx, const double* Dabs, int32_t d, int
 int gpbo_reserve_appends(gpbo_ctx* ctx, int64_t max_appends);
 
 /* -logL (mlefcn, BayesOpt_v4.ipynb:154-165) and, when grad_out != NULL, its gradient
- * w.r.t. theta (jacmlefun, GP/BayesOpt_v3.m:392-417; RBF only) for B settings.
+ * w.r.t. theta (jacmlefun, GP/BayesOpt_v3.m:392-417; the Matern-5/2 form has no reference counterpart) for B settings.
  * thetas is (B,d), sigmas (B,), nll_out (B,), grad_out (B,d).  status_out (B,) may be
  * NULL; a non-PD setting yields nll = NaN and status GPBO_ERR_NOT_PD for that entry. */
 int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d,

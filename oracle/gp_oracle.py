@@ -188,17 +188,18 @@ def mlefcn(xTrain, yTrain, theta, sigmaY, kernel=RBF):
     return n / 2 * (math.log(2 * math.pi) + 1) + n / 2 * math.log(theta1) + float(np.sum(np.log(np.diag(L))))
 
 
-def mle_grad(xTrain, yTrain, theta, sigmaY):
-    """Analytic d(-logL)/d theta_i, RBF only.  Restates jacmlefun
+def mle_grad(xTrain, yTrain, theta, sigmaY, kernel=RBF):
+    """Analytic d(-logL)/d theta_i.  Restates jacmlefun
     (GP/BayesOpt_v3.m:392-417; MATLAB text, cannot be executed here):
       dK_i = Dsq_i o (L L^T) / theta_i^3,
       J_i  = -1/2 ( n a^T dK_i a / (y^T a) - tr((L L^T)^{-1} dK_i) ).
+    Matern-5/2 (no reference implementation): dK_i = Dsq_i / theta_i^3 * (5/3)(1 + s) exp(-s), s = sqrt(5 D).
     Pinned by central differences of mlefcn in the tests."""
     X = np.asarray(xTrain, dtype=np.float64)
     y = np.asarray(yTrain, dtype=np.float64).reshape(-1)
     theta = np.asarray(theta, dtype=np.float64).reshape(-1)
     n, d = X.shape
-    K = kernel_matrix(X, X, theta, RBF) + jitter(n, sigmaY) * np.eye(n)
+    K = kernel_matrix(X, X, theta, kernel) + jitter(n, sigmaY) * np.eye(n)
     L = np.linalg.cholesky(K)
     a = solve_triangular(L, y, lower=True)
     a = solve_triangular(L, a, lower=True, trans='T')
@@ -206,9 +207,14 @@ def mle_grad(xTrain, yTrain, theta, sigmaY):
     Kinv = W.T @ W
     g = np.empty(d)
     ya = float(y @ a)
+    if kernel == RBF:
+        F = K                                   # -2 dk/d(r^2) = k for the RBF kernel
+    else:
+        s5r = np.sqrt(5.0 * scaled_sqdist(X, X, theta))
+        F = (5.0 / 3.0) * (1.0 + s5r) * np.exp(-s5r)
     for i in range(d):
         Dsq = (X[:, i][:, None] - X[:, i][None, :]) ** 2
-        dK = Dsq * K / theta[i] ** 3
+        dK = Dsq * F / theta[i] ** 3
         g[i] = -0.5 * (n * float(a @ dK @ a) / ya - float(np.sum(Kinv * dK)))
     return g
 

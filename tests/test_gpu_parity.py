@@ -385,3 +385,21 @@ def test_small_n_fused_likelihood_equals_the_general_path(gp0):
     assert good.sum() >= B // 2
     assert np.max(np.abs(nll[good] - z['nll'][good]) / np.maximum(1.0, np.abs(nll[good]))) <= 1e-9
     assert np.max(np.abs(grad[good] - z['grad'][good])) <= 1e-7 * max(1.0, np.max(np.abs(grad[good])))
+
+
+@pytest.mark.parametrize('n', [60, 300])
+def test_matern_gradient_small_and_general_path(gp0, n):
+    """Matern-5/2 -logL gradient (no reference counterpart; the oracle's is pinned by finite differences):
+    n = 60 runs the one-workgroup kernel, n = 300 the tile-engine path."""
+    d = 3
+    X = o.splitmix64_uniform(23, n * d).reshape(n, d)
+    y = np.cos(3 * X[:, 0]) + X[:, 1] - X[:, 2] ** 2
+    thetas = np.array([[0.4, 0.6, 0.5], [0.25, 0.3, 0.9], [0.8, 0.7, 0.6]])
+    sigmas = np.array([0.1, 0.05, 0.2])
+    nll, grad, stat = gp0.lml_batch(X, y, thetas, sigmas, kernel=bo.KERNEL_MATERN52, grad=True)
+    assert np.all(stat == 0)
+    for b in range(3):
+        ref = o.mlefcn(X, y, thetas[b], sigmas[b], kernel=o.MATERN52)
+        gref = o.mle_grad(X, y, thetas[b], sigmas[b], kernel=o.MATERN52)
+        assert abs(nll[b] - ref) <= 1e-9 * max(1.0, abs(ref))
+        assert np.max(np.abs(grad[b] - gref)) <= 1e-7 * max(1.0, np.max(np.abs(gref)))

@@ -116,3 +116,18 @@ def test_splitmix_shards_are_slices():
     a = o.splitmix64_uniform(9, 1000)
     b = np.concatenate([o.splitmix64_uniform(9, 400), o.splitmix64_uniform(9, 600, offset=400)])
     assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 1 and abs(a.mean() - 0.5) < 0.05
+
+
+def test_oracle_matern_gradient_against_central_differences():
+    """No reference implementation of the Matern-5/2 gradient: pinned by central differences of the oracle's own mlefcn."""
+    n, d = 40, 3
+    X = o.splitmix64_uniform(17, n * d).reshape(n, d)
+    y = np.cos(3 * X[:, 0]) + X[:, 1] - X[:, 2] ** 2
+    for theta, s in ((np.array([0.4, 0.6, 0.5]), 0.1), (np.array([0.25, 0.3, 0.9]), 0.02)):
+        g = o.mle_grad(X, y, theta, s, kernel=o.MATERN52)
+        h = 1e-6
+        for i in range(d):
+            e = np.zeros(d)
+            e[i] = h
+            fd = (o.mlefcn(X, y, theta + e, s, kernel=o.MATERN52) - o.mlefcn(X, y, theta - e, s, kernel=o.MATERN52)) / (2 * h)
+            assert abs(g[i] - fd) <= 1e-5 * max(1.0, abs(fd)), (i, g[i], fd)
