@@ -26,7 +26,7 @@ def _lml_gp(device=0):
     return _ctx[device]
 
 
-def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, steprule, max_its, W0, device=0):
+def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, steprule, max_its, W0, device=0, kernel=0):
     """All rows of W0 (nruns, d) advance in lockstep.  Returns (weight_history, cost_history, exitflag):
     weight_history[r] is the list of iterates of start r, cost_history[r] the -logL at each of them."""
     if steprule == 'backtrack':
@@ -36,7 +36,7 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
     nruns, d = W.shape
     tol = 1e-10
     sig = np.full(nruns, float(sigmaY))
-    nll, grad, stat = gp.lml_batch(xTrain, yTrain, W, sig, grad=True)
+    nll, grad, stat = gp.lml_batch(xTrain, yTrain, W, sig, kernel=kernel, grad=True)
     cost = np.where(stat == 0, nll, np.inf)
     w_hist = [[W[r].copy()] for r in range(nruns)]
     c_hist = [[cost[r]] for r in range(nruns)]
@@ -58,7 +58,7 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
             alpha_r[:] = 1.0 / k
         Wn[~active] = W[~active]
         moved = np.linalg.norm(Wn - W, axis=1)
-        nll, gnew, stat = gp.lml_batch(xTrain, yTrain, Wn, sig, grad=True)
+        nll, gnew, stat = gp.lml_batch(xTrain, yTrain, Wn, sig, kernel=kernel, grad=True)
         for r in range(nruns):
             if not active[r]:
                 continue
@@ -80,20 +80,21 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
     return w_hist, c_hist, exitflag
 
 
-def hypopt(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain, Daa, sigmaY, x0=None):
+def hypopt(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain, Daa, sigmaY, x0=None, kernel=0):
     """Signature of BayesOpt_v4.ipynb:167-178 (Daa is accepted and ignored; distances are rebuilt on the device).
-    x0: optional (nruns, d) starting points; default np.random.rand like the reference."""
+    x0: optional (nruns, d) starting points; default np.random.rand like the reference.  kernel: 0 RBF (the reference's),
+    1 Matern-5/2."""
     d = np.asarray(xTrain).shape[1]
     if x0 is None:
         x0 = np.array([np.random.rand(d) for _ in range(int(nruns))])
     w_hist, c_hist, flags = conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, normrule, steprule,
-                                                          int(max_its), x0)
+                                                          int(max_its), x0, kernel=kernel)
     return w_hist, c_hist, list(flags)
 
 
-def hypopt_wrap(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain, Daa, sigmaY, x0=None):
+def hypopt_wrap(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain, Daa, sigmaY, x0=None, kernel=0):
     """Signature of BayesOpt_v4.ipynb:180-186: the final iterate of the start with the lowest final cost."""
-    param_cont, cost_cont, flag_cont = hypopt(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain, Daa, sigmaY, x0)
+    param_cont, cost_cont, flag_cont = hypopt(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain, Daa, sigmaY, x0, kernel)
     ff = np.array([c[-1] if np.isfinite(c[-1]) else (c[-2] if len(c) > 1 else np.inf) for c in cost_cont])
     iopt = int(np.argmin(ff))
     last = param_cont[iopt][-1] if np.isfinite(cost_cont[iopt][-1]) else param_cont[iopt][-2]
