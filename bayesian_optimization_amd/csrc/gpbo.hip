@@ -342,8 +342,9 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     const int nb = (int)ctx->nb;
     const int G = chol_group(nb);
     // The two-stream form is opt-in (GPBO_CHOL_LOOKAHEAD=1): it is 10-25 % faster from n = 16384 up with the GPU to
-    // itself, but with other processes on the same GPU (two ranks and a parent sharing one card) the cross-stream
-    // waits were seen to stall indefinitely.
+    // itself, but with other processes on the same GPU (two ranks and a parent sharing one card) every cross-stream
+    // wait took ~0.5 s and progress then stopped: with more user queues than hardware queue slots the scheduler
+    // time-slices the queues, and a chain of waits between queues advances one slice at a time.
     bool la = false;
     if (const char* e = getenv("GPBO_CHOL_LOOKAHEAD")) la = atoi(e) != 0 && ctx->lookahead && nb > 3 * G;
     if (la) {
