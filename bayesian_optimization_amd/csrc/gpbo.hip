@@ -244,13 +244,11 @@ int chol_group(int nb) {
 }
 
 // F(group): the latency-bound part.  Needs the group's block columns up to date.
-// excl: the diagonal-block kernel asks for a CU of its own (see k_potrf_diag).
-void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, int p0, int g, bool excl) {
+void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, int p0, int g) {
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
     for (int q = p0; q < p0 + g; ++q) {
-        if (excl) hipLaunchKernelGGL(k_potrf_diag_excl, dim3(1), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev);
-        else hipLaunchKernelGGL(k_potrf_diag_shared, dim3(1), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev);
         if (q + 1 < nb) hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1), dim3(GEMM_THREADS), 0, st, A, ld, q, ctx->Dinv);
         const int rest = p0 + g - 1 - q;      // the group's block columns right of q take panel q at once (K = 128):
         if (rest > 0)                         // more tiles per launch and a shorter chain than one growing-K update per column
@@ -278,7 +276,7 @@ hipEvent_t sync_event(gpbo_ctx* ctx, size_t i) {
 // (1.6 ms, up to 12 ms) unless the bulk stream's CU mask leaves CUs free.  A mask that leaves out one CU per XCD
 // costs the bulk stream 13-19 % (the workgroup distributor deals evenly over shader engines, the short one sets
 // the pace) and is still the fastest combination at every size measured: masked bulk stream, exclusive diagonal
-// kernel.  GPBO_CHOL_MASK=0 selects the unmasked stream with the co-resident kernel.
+// kernel.  GPBO_CHOL_MASK=0 selects an unmasked bulk stream.
 int launch_cholesky_lookahead(gpbo_ctx* ctx, double* A, int* info_dev) {
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
@@ -308,7 +306,7 @@ int launch_cholesky_lookahead(gpbo_ctx* ctx, double* A, int* info_dev) {
     const int G = chol_group(nb);
     for (int p0 = 0; p0 < nb; p0 += G) {
         const int g = std::min(G, nb - p0);
-        chol_factor_group(P, ctx, A, info_dev, p0, g, masked);
+        chol_factor_group(P, ctx, A, info_dev, p0, g);
         const int c1 = p0 + g;                      // first block right of the group
         const int T = nb - c1;
         if (T <= 0) break;
@@ -352,7 +350,7 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     } else {
         for (int p0 = 0; p0 < nb; p0 += G) {
             const int g = std::min(G, nb - p0);
-            chol_factor_group(ctx->stream, ctx, A, info_dev, p0, g, true);
+            chol_factor_group(ctx->stream, ctx, A, info_dev, p0, g);
             const int T = nb - (p0 + g);
             if (T > 0)
                 hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T * (T + 1) / 2)), dim3(GEMM_THREADS), 0, ctx->stream, A, ld,

@@ -71,17 +71,14 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
 
 // ---------------------------------------------------------------------------------------
 
-// Diagonal block p: right-looking Cholesky of the 128x128 block, then its inverse, in one workgroup
-// of 256 threads.  The block is cut into 16x16 register tiles of 8x8; thread (tr, tc) owns tile
-// (tr, tc) (the 136 lower tiles do work).  Column step j: the owners of tile column j/8 publish the
-// raw column through a double-buffered 128-entry LDS vector, one barrier, then every thread scales by
-// 1/sqrt(pivot) and applies the rank-1 update to its 64 registers (static register indices: the
-// loop over the 8 columns of a tile column is unrolled).  The inverse is the same elimination run on
-// X = I: row j of X is published, rows below subtract L[r][j] * X[j][:].  256 barriers in total and
-// no redundant arithmetic, against 128 rows x 8 lanes recomputing every pivot in a reduction form
-// that ran at 3,600 cycles per column.
+// Diagonal block p of the blocked factorisation: Cholesky factor of the 128x128 block and its inverse in one
+// workgroup of 256 threads, both on a packed copy of the lower triangle in LDS (potrf128_lds: eight 16-column panels;
+// trinv128_lds: recursive doubling).  0.14 ms per block; a column-by-column elimination of the whole block on
+// register tiles (256 barriers) took 0.19 ms, a reduction form 0.38 ms.
 // Writes L (lower, zeros above) back into A and inv(L) (lower, zeros above) into Dinv.
 // info: first failing 1-based global row (pivot <= 0 or NaN), set once.
+// The register-tile elimination (potrf_factor_regs / potrf_inverse_regs) is kept for the one-workgroup likelihood
+// kernel, whose covariance tiles are born in registers.
 constexpr int POTRF_THREADS = 256;
 // The inverse phase reads L from a packed lower-triangular LDS copy (row r starts at r (r + 1) / 2); a wave reads four
 // distinct addresses per access (one per tile row): broadcasts, no bank conflicts.  The LDS request is padded to
@@ -89,7 +86,6 @@ constexpr int POTRF_THREADS = 256;
 // fit on a CU that holds a tile-engine workgroup (72 KB of 160).
 __device__ __forceinline__ constexpr int tri_off(int r) { return r * (r + 1) / 2; }
 constexpr int POTRF_LDS_PACKED = PB * (PB + 1) / 2;     // 8256 doubles
-constexpr int POTRF_LDS_EXCL = 11520;                   // padded: 94 KB with the vectors below
 // Factor phase on register tiles.  vec: [2][PB] LDS, dg: [PB] LDS (receives diag L).  Returns the first failing
 // column (pivot <= 0 or NaN) or -1.  All 256 threads must call it; it ends without a barrier after the last step.
 __device__ __forceinline__ int potrf_factor_regs(double (&a)[8][8], double* __restrict__ vec, double* __restrict__ dg) {
@@ -192,68 +188,236 @@ __device__ __forceinline__ void potrf_inverse_regs(double (&a)[8][8], const doub
     }
 }
 
+// Cholesky factor of the 128x128 block held packed in LDS (M, row r at tri_off(r)), in place, right-looking over eight
+// 16-column panels: (a) the 16x16 diagonal block by ONE wave (row i in lane i & 15, four columns per lane, the pivot
+// column exchanged through LDS; no workgroup barrier inside), (b) the rows below by substitution, one thread per row,
+// (c) the rank-16 update of the trailing triangle on 4x4 register blocks.  24 barriers instead of the 128 of a
+// column-by-column elimination over the whole block.  *failp (LDS, preset to -1) receives the first column whose
+// pivot is <= 0 or NaN.  All 256 threads must call it; ends on a barrier.
+__device__ __forceinline__ void potrf128_lds(double* __restrict__ M, int* __restrict__ failp) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int jb = 0; jb < 8; ++jb) {
+        const int c0 = 16 * jb;
+        if (w == 0) {
+            const int i = lane & 15, g = lane >> 4;
+            double v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (4 * g + e <= i) ? M[tri_off(c0 + i) + c0 + 4 * g + e] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (g == (j >> 2) && i >= j) M[tri_off(c0 + i) + c0 + j] = v[j & 3];      // publish column j as it stands
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double piv = M[tri_off(c0 + j) + c0 + j];
+                if (!(piv > 0.0) && lane == 0 && *failp < 0) *failp = c0 + j;
+                const double d = sqrt(piv);
+                const double rd = 1.0 / d;
+                const double lij = (i > j) ? M[tri_off(c0 + i) + c0 + j] * rd : 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * g + e;
+                    if (c > j && c <= i) v[e] = fma(-lij, M[tri_off(c0 + c) + c0 + j] * rd, v[e]);
+                }
+                if (g == (j >> 2)) {
+                    if (i == j) v[j & 3] = d;
+                    else if (i > j) v[j & 3] = lij;
+                }
+                __builtin_amdgcn_wave_barrier();     // every lane has read column j before the next publish overwrites LDS
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e <= i) M[tri_off(c0 + i) + c0 + 4 * g + e] = v[e];
+        }
+        __syncthreads();
+        const int r1 = c0 + 16;                      // first row below the panel's diagonal block
+        const int nrows = PB - r1;
+        if (tid < nrows) {                           // x L11^T = b, row r1 + tid
+            const int r = r1 + tid;
+            double x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double sacc = M[tri_off(r) + c0 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) sacc = fma(-x[k], M[tri_off(c0 + j) + c0 + k], sacc);
+                x[j] = sacc / M[tri_off(c0 + j) + c0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) M[tri_off(r) + c0 + j] = x[j];
+        }
+        __syncthreads();
+        const int n4 = nrows >> 2;                   // trailing triangle in 4x4 blocks
+        const int nblk = n4 * (n4 + 1) / 2;
+        for (int blk = tid; blk < nblk; blk += POTRF_THREADS) {
+            int bi, bj;
+            tri_decode(blk, bi, bj);
+            const int ra = r1 + 4 * bi, qa = r1 + 4 * bj;
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                double lr[4], lc[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    lr[a] = M[tri_off(ra + a) + c0 + k];
+                    lc[a] = M[tri_off(qa + a) + c0 + k];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(lr[a], lc[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (qa + b <= ra + a) M[tri_off(ra + a) + qa + b] -= acc[a][b];
+        }
+        __syncthreads();
+    }
+}
+
+// Inverse of the 128x128 lower-triangular block held packed in LDS (M, row r at tri_off(r)), in place, by recursive
+// doubling: the eight 16x16 diagonal blocks by substitution (one thread per column), then three levels
+//   W[B,A] = -W[B,B] (L[B,A] W[A,A])      with half sizes 16, 32, 64,
+// each as two small triangular products on register blocks, the intermediate product in T.  About ten barriers
+// instead of the 128 sequential steps of an elimination.  All 256 threads must call it; ends on a barrier.
+template <int S, int BR, int BC>
+__device__ __forceinline__ void trinv_level(double* __restrict__ M, double* __restrict__ T) {
+    constexpr int P = PB / (2 * S);
+    constexpr int NBR = S / BR, NBC = S / BC;
+    constexpr int TOTAL = P * NBR * NBC;
+    static_assert(TOTAL <= POTRF_THREADS, "one register block per thread");
+    const int tid = threadIdx.x;
+    const bool act = tid < TOTAL;
+    const int p = tid / (NBR * NBC), rem = tid % (NBR * NBC);
+    const int i0 = (rem / NBC) * BR, j0 = (rem % NBC) * BC;
+    const int a0 = 2 * p * S, b0 = a0 + S;
+    double* Tp = T + p * S * (S + 1);
+    double acc[BR][BC];
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r)
+#pragma unroll
+            for (int c = 0; c < BC; ++c) acc[r][c] = 0.0;
+        for (int k = j0; k < S; ++k) {           // T = L[B,A] W[A,A], W[A,A] lower: k >= j
+            double lv[BR], wv[BC];
+#pragma unroll
+            for (int r = 0; r < BR; ++r) lv[r] = M[tri_off(b0 + i0 + r) + a0 + k];
+#pragma unroll
+            for (int c = 0; c < BC; ++c) {
+                const double w = M[tri_off(a0 + k) + a0 + j0 + c];
+                wv[c] = (k >= j0 + c) ? w : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < BR; ++r)
+#pragma unroll
+                for (int c = 0; c < BC; ++c) acc[r][c] = fma(lv[r], wv[c], acc[r][c]);
+        }
+#pragma unroll
+        for (int r = 0; r < BR; ++r)
+#pragma unroll
+            for (int c = 0; c < BC; ++c) Tp[(i0 + r) * (S + 1) + j0 + c] = acc[r][c];
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r)
+#pragma unroll
+            for (int c = 0; c < BC; ++c) acc[r][c] = 0.0;
+        for (int k = 0; k < i0 + BR; ++k) {      // W[B,A] = -W[B,B] T, W[B,B] lower: k <= i
+            double wv[BR], tv[BC];
+#pragma unroll
+            for (int r = 0; r < BR; ++r) {
+                const double w = M[tri_off(b0 + i0 + r) + b0 + k];
+                wv[r] = (k <= i0 + r) ? w : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < BC; ++c) tv[c] = Tp[k * (S + 1) + j0 + c];
+#pragma unroll
+            for (int r = 0; r < BR; ++r)
+#pragma unroll
+                for (int c = 0; c < BC; ++c) acc[r][c] = fma(wv[r], tv[c], acc[r][c]);
+        }
+        // L[B,A] was last read before the barrier above; step 2 reads only W[B,B] and T
+#pragma unroll
+        for (int r = 0; r < BR; ++r)
+#pragma unroll
+            for (int c = 0; c < BC; ++c) M[tri_off(b0 + i0 + r) + a0 + j0 + c] = -acc[r][c];
+    }
+    __syncthreads();
+}
+
+constexpr int TRINV_T_DOUBLES = 64 * 65;
+__device__ __forceinline__ void trinv128_lds(double* __restrict__ M, double* __restrict__ T) {
+    const int tid = threadIdx.x;
+    double x[16];
+    const int q = (tid >> 4) & 7, c = tid & 15, base = 16 * q;
+    if (tid < 128) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc = fma(-M[tri_off(base + i) + base + k], x[k], sacc);
+            x[i] = sacc / M[tri_off(base + i) + base + i];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i >= c) M[tri_off(base + i) + base + c] = x[i];
+    }
+    __syncthreads();
+    trinv_level<16, 1, 4>(M, T);
+    trinv_level<32, 2, 4>(M, T);
+    trinv_level<64, 4, 4>(M, T);
+}
+
 __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
                                                 int* __restrict__ info, double* __restrict__ S) {
-    __shared__ double vec[2 * PB];      // published column (factor) / row (inverse), double buffered
-    __shared__ double dg[PB];           // diagonal of L
+    __shared__ int fail_s;
     const int tid = threadIdx.x;
-    const int tr = tid >> 4, tc = tid & 15;
     double* blk = A + (long)p * PB * ld + (long)p * PB;
-    double a[8][8];
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; cc += 2) {
-            const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)(tr * 8 + rr) * ld + tc * 8 + cc);
-            a[rr][cc] = v.x;
-            a[rr][cc + 1] = v.y;
+    if (tid == 0) fail_s = -1;
+    for (int idx = tid; idx < PB * PB / 2; idx += POTRF_THREADS) {      // lower triangle -> packed LDS
+        const int r = idx >> 6, c = (idx & 63) * 2;
+        if (c <= r) {
+            const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)r * ld + c);
+            S[tri_off(r) + c] = v.x;
+            if (c + 1 <= r) S[tri_off(r) + c + 1] = v.y;
         }
-    const int fail = potrf_factor_regs(a, vec, dg);
-    if (tid == 0 && fail >= 0) atomicCAS(info, 0, p * PB + fail + 1);
-    // L -> global (zeros above the diagonal) and -> LDS for the inverse
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            const int r = tr * 8 + rr, c = tc * 8 + cc;
-            if (c <= r) S[tri_off(r) + c] = a[rr][cc];
-        }
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; cc += 2) {
-            const int r = tr * 8 + rr, c = tc * 8 + cc;
-            f64x2 v;
-            v.x = (c <= r) ? a[rr][cc] : 0.0;
-            v.y = (c + 1 <= r) ? a[rr][cc + 1] : 0.0;
-            *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
-        }
+    }
     __syncthreads();
-    potrf_inverse_regs(a, S, vec, dg);
+    potrf128_lds(S, &fail_s);
+    if (tid == 0 && fail_s >= 0) atomicCAS(info, 0, p * PB + fail_s + 1);
+    for (int idx = tid; idx < PB * PB / 2; idx += POTRF_THREADS) {      // L -> global, zeros above the diagonal
+        const int r = idx >> 6, c = (idx & 63) * 2;
+        f64x2 v;
+        v.x = (c <= r) ? S[tri_off(r) + c] : 0.0;
+        v.y = (c + 1 <= r) ? S[tri_off(r) + c + 1] : 0.0;
+        *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
+    }
+    __syncthreads();
+    trinv128_lds(S, S + POTRF_LDS_PACKED);
     double* dinv = Dinv + (long)p * PB * PB;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; cc += 2) {
-            const int r = tr * 8 + rr, c = tc * 8 + cc;
-            f64x2 v;
-            v.x = (c <= r) ? a[rr][cc] : 0.0;
-            v.y = (c + 1 <= r) ? a[rr][cc + 1] : 0.0;
-            *reinterpret_cast<f64x2*>(dinv + r * PB + c) = v;
-        }
+    for (int idx = tid; idx < PB * PB / 2; idx += POTRF_THREADS) {
+        const int r = idx >> 6, c = (idx & 63) * 2;
+        f64x2 v;
+        v.x = (c <= r) ? S[tri_off(r) + c] : 0.0;
+        v.y = (c + 1 <= r) ? S[tri_off(r) + c + 1] : 0.0;
+        *reinterpret_cast<f64x2*>(dinv + r * PB + c) = v;
+    }
 }
 
-// Alone on its CU: padded LDS request, all the registers it wants.
-__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag_excl(double* __restrict__ A, long ld, int p,
-                                                                   double* __restrict__ Dinv, int* __restrict__ info) {
-    __shared__ double S[POTRF_LDS_EXCL];
-    potrf_diag_body(A, ld, p, Dinv, info, S);
-}
-
-// Beside one tile-engine workgroup (72 KB LDS, 224 registers per wave): 69 KB and at most 256 registers.
-__global__ __launch_bounds__(POTRF_THREADS, 2) void k_potrf_diag_shared(double* __restrict__ A, long ld, int p,
-                                                                        double* __restrict__ Dinv, int* __restrict__ info) {
-    __shared__ double S[POTRF_LDS_PACKED];
+// The LDS request (packed L + the product buffer of the inverse, 99 KB) keeps every tile-engine workgroup (72 KB of
+// 160) off the CU: the kernel is latency bound and runs 4x slower when its waves share SIMDs with MFMA waves.
+__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
+                                                              double* __restrict__ Dinv, int* __restrict__ info) {
+    __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES];
     potrf_diag_body(A, ld, p, Dinv, info, S);
 }
 

@@ -15,7 +15,7 @@ int main() {
         (void)hipMemset(info, 0, 64);
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0);
-        k_potrf_diag_excl<<<1, POTRF_THREADS>>>(dA, n, 0, dinv, info);
+        k_potrf_diag<<<1, POTRF_THREADS>>>(dA, n, 0, dinv, info);
         (void)hipEventRecord(e1);
         (void)hipDeviceSynchronize();
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
