@@ -194,13 +194,21 @@ __device__ __forceinline__ void potrf_inverse_regs(double (&a)[8][8], const doub
 // (c) the rank-16 update of the trailing triangle on 4x4 register blocks.  24 barriers instead of the 128 of a
 // column-by-column elimination over the whole block.  *failp (LDS, preset to -1) receives the first column whose
 // pivot is <= 0 or NaN.  All 256 threads must call it; ends on a barrier.
+#ifdef GPBO_STAMPS
+__device__ long long g_stamps[64];
+#define GPBO_STAMP(i, acc) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); if (acc) g_stamps[i] += t_ - g_stamps[63]; g_stamps[63] = t_; } } while (0)
+#else
+#define GPBO_STAMP(i, acc) do { } while (0)
+#endif
 __device__ __forceinline__ void potrf128_lds(double* __restrict__ M, int* __restrict__ failp) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int jb = 0; jb < 8; ++jb) {
         const int c0 = 16 * jb;
+        GPBO_STAMP(0, 0);
         if (w == 0) {
             const int i = lane & 15, g = lane >> 4;
             double v[4];
+            int fail = -1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (4 * g + e <= i) ? M[tri_off(c0 + i) + c0 + 4 * g + e] : 0.0;
 #pragma unroll
@@ -209,15 +217,28 @@ __device__ __forceinline__ void potrf128_lds(double* __restrict__ M, int* __rest
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // all six reads are issued together; the square root works on the first while the rest arrive
                 const double piv = M[tri_off(c0 + j) + c0 + j];
-                if (!(piv > 0.0) && lane == 0 && *failp < 0) *failp = c0 + j;
-                const double d = sqrt(piv);
-                const double rd = 1.0 / d;
-                const double lij = (i > j) ? M[tri_off(c0 + i) + c0 + j] * rd : 0.0;
+                const double rij = M[tri_off(c0 + (i > j ? i : j)) + c0 + j];
+                double rc[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 4 * g + e;
-                    if (c > j && c <= i) v[e] = fma(-lij, M[tri_off(c0 + c) + c0 + j] * rd, v[e]);
+                    rc[e] = M[tri_off(c0 + (c > j ? c : j)) + c0 + j];
+                }
+                if (!(piv > 0.0) && fail < 0) fail = c0 + j;
+                // 1/sqrt from the hardware estimate and two Newton steps, sqrt as piv * (1/sqrt) with one correction:
+                // a dozen dependent operations instead of the ~45 of a correctly rounded sqrt followed by a division
+                double rd = __builtin_amdgcn_rsq(piv);
+                rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
+                rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
+                double d = piv * rd;
+                d = fma(0.5 * rd, fma(-d, d, piv), d);
+                const double lij = (i > j) ? rij * rd : 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * g + e;
+                    if (c > j && c <= i) v[e] = fma(-lij, rc[e] * rd, v[e]);
                 }
                 if (g == (j >> 2)) {
                     if (i == j) v[j & 3] = d;
@@ -228,8 +249,10 @@ __device__ __forceinline__ void potrf128_lds(double* __restrict__ M, int* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (4 * g + e <= i) M[tri_off(c0 + i) + c0 + 4 * g + e] = v[e];
+            if (lane == 0 && fail >= 0 && *failp < 0) *failp = fail;
         }
         __syncthreads();
+        GPBO_STAMP(1, 1);
         const int r1 = c0 + 16;                      // first row below the panel's diagonal block
         const int nrows = PB - r1;
         if (tid < nrows) {                           // x L11^T = b, row r1 + tid
@@ -246,6 +269,7 @@ __device__ __forceinline__ void potrf128_lds(double* __restrict__ M, int* __rest
             for (int j = 0; j < 16; ++j) M[tri_off(r) + c0 + j] = x[j];
         }
         __syncthreads();
+        GPBO_STAMP(2, 1);
         const int n4 = nrows >> 2;                   // trailing triangle in 4x4 blocks
         const int nblk = n4 * (n4 + 1) / 2;
         for (int blk = tid; blk < nblk; blk += POTRF_THREADS) {
@@ -277,6 +301,7 @@ __device__ __forceinline__ void potrf128_lds(double* __restrict__ M, int* __rest
                     if (qa + b <= ra + a) M[tri_off(ra + a) + qa + b] -= acc[a][b];
         }
         __syncthreads();
+        GPBO_STAMP(3, 1);
     }
 }
 
@@ -392,7 +417,9 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
         }
     }
     __syncthreads();
+    GPBO_STAMP(4, 0);
     potrf128_lds(S, &fail_s);
+    GPBO_STAMP(5, 0);
     if (tid == 0 && fail_s >= 0) atomicCAS(info, 0, p * PB + fail_s + 1);
     for (int idx = tid; idx < PB * PB / 2; idx += POTRF_THREADS) {      // L -> global, zeros above the diagonal
         const int r = idx >> 6, c = (idx & 63) * 2;
@@ -402,7 +429,9 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
         *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
     }
     __syncthreads();
+    GPBO_STAMP(6, 1);
     trinv128_lds(S, S + POTRF_LDS_PACKED);
+    GPBO_STAMP(7, 1);
     double* dinv = Dinv + (long)p * PB * PB;
     for (int idx = tid; idx < PB * PB / 2; idx += POTRF_THREADS) {
         const int r = idx >> 6, c = (idx & 63) * 2;

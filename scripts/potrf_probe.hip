@@ -1,4 +1,5 @@
 // Debug probe: in-kernel cycle stamps of k_potrf_diag (load / factor / inverse+store) and the clock it runs at.
+#define GPBO_STAMPS 1
 #include "../bayesian_optimization_amd/csrc/kernels.hpp"
 #include <cstdio>
 #include <vector>
@@ -13,6 +14,7 @@ int main() {
     for (int rep = 0; rep < 5; ++rep) {
         (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         (void)hipMemset(info, 0, 64);
+        { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0);
         k_potrf_diag<<<1, POTRF_THREADS>>>(dA, n, 0, dinv, info);
@@ -29,6 +31,7 @@ int main() {
                 for (int k = 0; k < n; ++k) { s1 += L[i * n + k] * L[j * n + k]; s2 += W[i * n + k] * L[k * n + j]; }
                 e1m = fmax(e1m, fabs(s1 - A[i * n + j])); e2m = fmax(e2m, fabs(s2 - (i == j)));
             }
+        { long long z[64]; (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_stamps), sizeof(z)); printf("ticks(100MHz): potrf16 %lld trsm %lld update %lld storeL %lld inverse %lld\n", z[1], z[2], z[3], z[6], z[7]); }
         printf("event %.1f us  |LL^T - A| %.2e  |WL - I| %.2e\n", ms * 1e3, e1m, e2m);
     }
     return 0;
