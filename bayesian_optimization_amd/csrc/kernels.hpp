@@ -582,10 +582,19 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict_
     if (tid < PB) yp[tid] = w[p * PB + tid];
     __syncthreads();
     const double* dinv = Dinv + (long)p * PB * PB;
-    for (int r = wv; r < PB; r += 4) {
-        double s = dinv[r * PB + lane] * yp[lane] + dinv[r * PB + 64 + lane] * yp[64 + lane];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) zp[r] = s;
+    const double y0 = yp[lane], y1 = yp[64 + lane];
+    for (int r0 = wv; r0 < PB; r0 += 32) {          // eight rows per batch: their loads are in flight together
+        double s[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u;
+            s[u] = dinv[r * PB + lane] * y0 + dinv[r * PB + 64 + lane] * y1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
+            if (lane == 0) zp[r0 + 4 * u] = s[u];
+        }
     }
     __syncthreads();
     if (blockIdx.x == 0) {
@@ -594,10 +603,19 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict_
     }
     const int ib = p + blockIdx.x;
     const double* Lp = L + (long)ib * PB * ld + (long)p * PB;
-    for (int r = wv; r < PB; r += 4) {
-        double s = Lp[(long)r * ld + lane] * zp[lane] + Lp[(long)r * ld + 64 + lane] * zp[64 + lane];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) w[ib * PB + r] -= s;
+    const double z0 = zp[lane], z1 = zp[64 + lane];
+    for (int r0 = wv; r0 < PB; r0 += 32) {
+        double s[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u;
+            s[u] = Lp[(long)r * ld + lane] * z0 + Lp[(long)r * ld + 64 + lane] * z1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
+            if (lane == 0) w[ib * PB + r0 + 4 * u] -= s[u];
+        }
     }
 }
 
@@ -615,6 +633,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
     const int c = tid & 127, hh = tid >> 7;
     {
         double s = 0.0;
+#pragma unroll 16
         for (int r = hh * 64; r < hh * 64 + 64; ++r) s += dinv[r * PB + c] * zp[r];
         red[tid] = s;
     }
@@ -628,6 +647,7 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
     const int jb = blockIdx.x - 1;
     const double* Lp = L + (long)p * PB * ld + (long)jb * PB;
     double s = 0.0;
+#pragma unroll 16
     for (int r = hh * 64; r < hh * 64 + 64; ++r) s += Lp[(long)r * ld + c] * xp[r];
     red[tid] = s;
     __syncthreads();
