@@ -6,7 +6,9 @@ compute layer fails with an explicit message telling how to build it.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgpbo.so')
@@ -77,6 +79,30 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own copy of the HIP and HSA runtimes and load them by path.  libgpbo.so names its HIP
+    runtime by soname, so whichever copy is mapped first serves it: loaded after torch it shares torch's runtime, loaded
+    before torch the process ends up with two runtimes side by side (device pointers handed between them, two sets of
+    queues).  When torch is installed but not imported yet, map its copies first so that there is one runtime whatever
+    the import order.  GPBO_SYSTEM_HIP=1 keeps the system runtime."""
+    if 'torch' in sys.modules or os.environ.get('GPBO_SYSTEM_HIP'):
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], 'lib')
+    for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load libgpbo.so once and attach the prototypes.  Raises ImportError when the
     library has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
@@ -87,6 +113,7 @@ def load():
         raise ImportError(
             'libgpbo.so not found at %s: the HIP extension is not built and there is no CPU '
             'fallback. Build it with: python -c "import __graft_entry__ as g; g.build()"' % LIB_PATH)
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = ABI mismatch, fail loudly
