@@ -61,6 +61,11 @@ struct gpbo_ctx {
     bool inc_valid = false;     // Vres/sres describe the current model and candidates
     std::vector<double> h_xnew;
 
+    // workspace of the one-workgroup likelihood kernel (n <= 128), kept between calls
+    double* sm_buf = nullptr;
+    size_t sm_cap = 0;          // doubles
+    std::vector<double> sm_host;
+
     // work contexts of the batched likelihood sweep (created on first use, kept for the next call)
     std::vector<gpbo_ctx*> lml_lanes;
 
@@ -684,6 +689,7 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     for (void* p : ps)
         if (p) hipFree(p);
     for (auto e : ctx->pool) hipEventDestroy(e);
+    if (ctx->sm_buf) hipFree(ctx->sm_buf);
     for (hipStream_t st : {ctx->pstream, ctx->bstream})
         if (st) {
             hipStreamSynchronize(st);
@@ -1251,60 +1257,53 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     bool small = (n_pad == PB && d <= GRAD_D);
     if (const char* e = getenv("GPBO_LML_SMALL")) small = small && atoi(e) != 0;
     if (small) {
-        double *Xraw = nullptr, *yd = nullptr, *thd = nullptr, *sgd = nullptr, *onll = nullptr, *ograd = nullptr;
-        int* infos = nullptr;
-        auto cleanup = [&]() {
-            for (void* p : {(void*)Xraw, (void*)yd, (void*)thd, (void*)sgd, (void*)onll, (void*)ograd, (void*)infos})
-                if (p) hipFree(p);
-        };
-#define SCHK(expr)                                                        \
-    do {                                                                  \
-        hipError_t e_ = (expr);                                           \
-        if (e_ != hipSuccess) {                                           \
-            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_); \
-            cleanup();                                                    \
-            return GPBO_ERR_HIP;                                          \
-        }                                                                 \
-    } while (0)
-        std::vector<double> xr((size_t)d * PB, 0.0), yp(PB, 0.0);
+        // one persistent device workspace, one upload, one launch, one download:
+        //   in : [Xraw d*128][y 128][thetas B*d][sigmas B]      out: [nll B][grad B*d][info B (as doubles)]
+        const size_t n_in = (size_t)d * PB + PB + (size_t)B * d + B;
+        const size_t n_out = (size_t)B + (size_t)B * d + B;
+        if (ctx->sm_cap < n_in + n_out) {
+            if (ctx->sm_buf) hipFree(ctx->sm_buf);
+            ctx->sm_buf = nullptr;
+            ctx->sm_cap = 0;
+            HIPCHK(hipMalloc((void**)&ctx->sm_buf, (n_in + n_out) * 8));
+            ctx->sm_cap = n_in + n_out;
+        }
+        std::vector<double>& h = ctx->sm_host;
+        h.assign(n_in + n_out, 0.0);
         for (int t = 0; t < d; ++t)
-            for (int64_t i = 0; i < n; ++i) xr[(size_t)t * PB + i] = X[i * d + t];
-        for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
-        SCHK(hipMalloc((void**)&Xraw, xr.size() * 8));
-        SCHK(hipMalloc((void**)&yd, PB * 8));
-        SCHK(hipMalloc((void**)&thd, (size_t)B * d * 8));
-        SCHK(hipMalloc((void**)&sgd, (size_t)B * 8));
-        SCHK(hipMalloc((void**)&onll, (size_t)B * 8));
-        SCHK(hipMalloc((void**)&ograd, (size_t)B * d * 8));
-        SCHK(hipMalloc((void**)&infos, (size_t)B * sizeof(int)));
-        SCHK(hipMemcpyAsync(Xraw, xr.data(), xr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        SCHK(hipMemcpyAsync(yd, yp.data(), PB * 8, hipMemcpyHostToDevice, ctx->stream));
-        SCHK(hipMemcpyAsync(thd, thetas, (size_t)B * d * 8, hipMemcpyHostToDevice, ctx->stream));
-        SCHK(hipMemcpyAsync(sgd, sigmas, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+            for (int64_t i = 0; i < n; ++i) h[(size_t)t * PB + i] = X[i * d + t];
+        double* hy = h.data() + (size_t)d * PB;
+        for (int64_t i = 0; i < n; ++i) hy[i] = y[i];
+        memcpy(hy + PB, thetas, (size_t)B * d * 8);
+        memcpy(hy + PB + (size_t)B * d, sigmas, (size_t)B * 8);
+        double* dX = ctx->sm_buf;
+        double* dy = dX + (size_t)d * PB;
+        double* dth = dy + PB;
+        double* dsg = dth + (size_t)B * d;
+        double* dnll = ctx->sm_buf + n_in;
+        double* dgrad = dnll + B;
+        int* dinfo = reinterpret_cast<int*>(dgrad + (size_t)B * d);
         const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_lml_small, dim3((unsigned)B), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)Xraw, (int)PB,
-                           (const double*)yd, (int)n, (int)d, (const double*)thd, (const double*)sgd, (int)kernel, grad_out ? 1 : 0,
-                           onll, ograd, infos);
-        SCHK(hipGetLastError());
-        std::vector<int> hinfo(B);
-        SCHK(hipMemcpyAsync(nll_out, onll, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (grad_out) SCHK(hipMemcpyAsync(grad_out, ograd, (size_t)B * d * 8, hipMemcpyDeviceToHost, ctx->stream));
-        SCHK(hipMemcpyAsync(hinfo.data(), infos, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SCHK(hipStreamSynchronize(ctx->stream));
-#undef SCHK
+        HIPCHK(hipMemcpyAsync(ctx->sm_buf, h.data(), n_in * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_lml_small, dim3((unsigned)B), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)dX, (int)PB,
+                           (const double*)dy, (int)n, (int)d, (const double*)dth, (const double*)dsg, (int)kernel, grad_out ? 1 : 0,
+                           dnll, dgrad, dinfo);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h.data() + n_in, dnll, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const double* onll = h.data() + n_in;
+        const double* ograd = onll + B;
+        const int* hinfo = reinterpret_cast<const int*>(ograd + (size_t)B * d);
         ctx->tm.fit_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ctx->tm.chol_count = B;
         ctx->tm.kbuild_ms = ctx->tm.chol_ms = ctx->tm.trsv_ms = ctx->tm.inverse_ms = 0;
         for (int b = 0; b < B; ++b) {
-            const bool bad = hinfo[b] != 0 || !std::isfinite(nll_out[b]);
+            const bool bad = hinfo[b] != 0 || !std::isfinite(onll[b]);
             if (status_out) status_out[b] = bad ? GPBO_ERR_NOT_PD : GPBO_OK;
-            if (bad) {
-                nll_out[b] = NAN;
-                if (grad_out)
-                    for (int t = 0; t < d; ++t) grad_out[(size_t)b * d + t] = NAN;
-            }
+            nll_out[b] = bad ? NAN : onll[b];
+            if (grad_out)
+                for (int t = 0; t < d; ++t) grad_out[(size_t)b * d + t] = bad ? NAN : ograd[(size_t)b * d + t];
         }
-        cleanup();
         return GPBO_OK;
     }
 
