@@ -102,11 +102,13 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
     const int a_off = frag_base<A_KCONTIG>(lane, wr * 64);
     const int b_off = TILE_DOUBLES + frag_base<B_KCONTIG>(lane, wc * 64);
     for (int k0 = k_begin; k0 < k_end; k0 += TK) {
-        const bool has_next = (k0 + TK) < k_end;
-        if (has_next) {
-            load_tile<A_KCONTIG>(sa, A, lda, k0 + TK, tid);
-            load_tile<B_KCONTIG>(sb, B, ldb, k0 + TK, tid);
-        }
+        // The loads and LDS stores of the next tile are unconditional (the last step re-reads its own tile into the
+        // buffer nobody reads any more), so the whole step is one basic block and the global loads can be placed one
+        // behind each of the first eight MFMAs instead of eight in a row in front of them.  (Refilling the register
+        // stage right after its LDS store, a whole k-step ahead, measured 10 % slower.)
+        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
+        load_tile<A_KCONTIG>(sa, A, lda, kn, tid);
+        load_tile<B_KCONTIG>(sb, B, ldb, kn, tid);
         const double* a_l = lds + buf * 2 * TILE_DOUBLES + a_off;
         const double* b_l = lds + buf * 2 * TILE_DOUBLES + b_off;
         double* nxt = lds + (buf ^ 1) * 2 * TILE_DOUBLES;
@@ -123,7 +125,14 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
-            if (kk == 2 && has_next) {   // the global data has had three k-substeps to arrive
+            if (kk == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            if (kk == 2) {   // the global data has had three k-substeps to arrive
                 store_tile<A_KCONTIG>(sa, nxt, tid);
                 store_tile<B_KCONTIG>(sb, nxt + TILE_DOUBLES, tid);
             }
