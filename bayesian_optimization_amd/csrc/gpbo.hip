@@ -245,7 +245,8 @@ int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, doub
 // updated once with K = 128*group.
 int chol_group(int nb) {
     if (const char* e = getenv("GPBO_CHOL_GROUP")) return std::max(1, atoi(e));
-    return nb >= 192 ? 8 : 4;      // large n: the panel stream is hidden, a longer K makes the bulk update more efficient
+    if (nb <= 40) return 1;        // small n: every launch is latency bound, one update per panel is the shortest chain
+    return nb >= 192 ? 8 : 4;      // large n: a longer K makes the bulk update more efficient
 }
 
 // F(group): the latency-bound part.  Needs the group's block columns up to date.
