@@ -66,6 +66,17 @@ struct gpbo_ctx {
     size_t sm_cap = 0;          // doubles
     std::vector<double> sm_host;
 
+    // batched likelihood sweep, general path: batch arrays (caller context) and per-lane state, all kept between calls
+    double *lb_xraw = nullptr, *lb_th = nullptr, *lb_sg = nullptr, *lb_nll = nullptr, *lb_grad = nullptr;
+    int* lb_info = nullptr;
+    size_t lb_xraw_cap = 0, lb_b_cap = 0, lb_bd_cap = 0;
+    double* lane_gpart = nullptr;
+    size_t lane_gpart_cap = 0;
+    LmlSlot* lane_slot = nullptr;
+    hipGraphExec_t lane_graph = nullptr;
+    std::vector<int64_t> lane_graph_key;
+    bool no_timing = false;     // set while a launch sequence is captured into a graph
+
     // work contexts of the batched likelihood sweep (created on first use, kept for the next call)
     std::vector<gpbo_ctx*> lml_lanes;
 
@@ -129,12 +140,14 @@ struct Scope {
     gpbo_ctx* ctx;
     EvRec r;
     Scope(gpbo_ctx* c, int cat) : ctx(c) {
+        if (c->no_timing) return;
         r.cat = cat;
         r.a = ev_get(c);
         r.b = ev_get(c);
         hipEventRecord(r.a, c->stream);
     }
     ~Scope() {
+        if (ctx->no_timing) return;
         hipEventRecord(r.b, ctx->stream);
         ctx->recs.push_back(r);
     }
@@ -230,11 +243,11 @@ int ensure_scratch(gpbo_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------- launch sequences
-int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, double eps) {
+int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, double eps, const double* eps_ptr = nullptr) {
     Scope s(ctx, T_KBUILD);
     dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4));
     hipLaunchKernelGGL(k_kernel_matrix, grid, dim3(256), 0, ctx->stream, ctx->Xts, (int)ctx->n, (int)ctx->n_pad, ctx->d, K,
-                       scale_ptr, eps, ctx->kernel);
+                       scale_ptr, eps, eps_ptr, ctx->kernel);
     HIPCHK(hipGetLastError());
     return GPBO_OK;
 }
@@ -691,6 +704,10 @@ void gpbo_destroy(gpbo_ctx* ctx) {
         if (p) hipFree(p);
     for (auto e : ctx->pool) hipEventDestroy(e);
     if (ctx->sm_buf) hipFree(ctx->sm_buf);
+    if (ctx->lane_graph) hipGraphExecDestroy(ctx->lane_graph);
+    for (void* p : {(void*)ctx->lb_xraw, (void*)ctx->lb_th, (void*)ctx->lb_sg, (void*)ctx->lb_nll, (void*)ctx->lb_grad,
+                    (void*)ctx->lb_info, (void*)ctx->lane_gpart, (void*)ctx->lane_slot})
+        if (p) hipFree(p);
     for (hipStream_t st : {ctx->pstream, ctx->bstream})
         if (st) {
             hipStreamSynchronize(st);
@@ -1322,35 +1339,60 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     }
     if (const char* e = getenv("GPBO_LML_STREAMS")) lanes = atoi(e);
     lanes = std::max(1, std::min(lanes, std::min<int>(B, 8)));
+    // Up to 16 panels a setting is ~30-150 launches of a few microseconds of GPU work each and the issuing host thread
+    // is the bottleneck (~6 us per launch; issuing from one thread per lane does not help, the launches serialise in
+    // the runtime): the sequence of one setting is captured once per lane into a graph and replayed.
+    bool use_graph = nb <= 16;
+    if (const char* e = getenv("GPBO_LML_GRAPH")) use_graph = atoi(e) != 0;
     std::vector<gpbo_ctx*> lane(lanes, nullptr);
     lane[0] = ctx;
     for (int l = 1; l < lanes && l - 1 < (int)ctx->lml_lanes.size(); ++l) lane[l] = ctx->lml_lanes[l - 1];
-    double *Xraw = nullptr, *th_dev = nullptr, *onll = nullptr, *ograd = nullptr;
-    std::vector<double*> gpart(lanes, nullptr);
-    int* infos = nullptr;
-    auto cleanup = [&]() {
-        for (int l = 0; l < lanes; ++l) {
-            if (lane[l]) hipStreamSynchronize(lane[l]->stream);
-            if (gpart[l]) hipFree(gpart[l]);
-        }
-        for (void* p : {(void*)Xraw, (void*)th_dev, (void*)onll, (void*)ograd, (void*)infos})
-            if (p) hipFree(p);
-        ctx->lookahead = true;         // lane 0 is the caller's context
+    auto fail_hip = [&](const char* what, hipError_t e) {
+        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        ctx->lookahead = true;
+        return GPBO_ERR_HIP;
     };
-#define LCHK(expr)                                                        \
-    do {                                                                  \
-        hipError_t e_ = (expr);                                           \
-        if (e_ != hipSuccess) {                                           \
-            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_); \
-            cleanup();                                                    \
-            return GPBO_ERR_HIP;                                          \
-        }                                                                 \
+#define LCHK(expr)                                         \
+    do {                                                   \
+        hipError_t e_ = (expr);                            \
+        if (e_ != hipSuccess) return fail_hip(#expr, e_);  \
     } while (0)
+    // batch arrays on the caller context, grown on demand (their addresses are part of the lanes' graph keys)
+    const size_t need_x = (size_t)d * n_pad, need_b = (size_t)B, need_bd = (size_t)B * d;
+    if (ctx->lb_xraw_cap < need_x) {
+        if (ctx->lb_xraw) hipFree(ctx->lb_xraw);
+        ctx->lb_xraw = nullptr;
+        ctx->lb_xraw_cap = 0;
+        LCHK(hipMalloc((void**)&ctx->lb_xraw, need_x * 8));
+        ctx->lb_xraw_cap = need_x;
+    }
+    if (ctx->lb_b_cap < need_b) {
+        for (void* p : {(void*)ctx->lb_sg, (void*)ctx->lb_nll, (void*)ctx->lb_info})
+            if (p) hipFree(p);
+        ctx->lb_sg = ctx->lb_nll = nullptr;
+        ctx->lb_info = nullptr;
+        ctx->lb_b_cap = 0;
+        const size_t cap = std::max<size_t>(64, need_b * 2);
+        LCHK(hipMalloc((void**)&ctx->lb_sg, cap * 8));
+        LCHK(hipMalloc((void**)&ctx->lb_nll, cap * 8));
+        LCHK(hipMalloc((void**)&ctx->lb_info, cap * sizeof(int)));
+        ctx->lb_b_cap = cap;
+    }
+    if (ctx->lb_bd_cap < need_bd) {
+        for (void* p : {(void*)ctx->lb_th, (void*)ctx->lb_grad})
+            if (p) hipFree(p);
+        ctx->lb_th = ctx->lb_grad = nullptr;
+        ctx->lb_bd_cap = 0;
+        const size_t cap = std::max<size_t>(64 * MAX_D, need_bd * 2);
+        LCHK(hipMalloc((void**)&ctx->lb_th, cap * 8));
+        LCHK(hipMalloc((void**)&ctx->lb_grad, cap * 8));
+        ctx->lb_bd_cap = cap;
+    }
     for (int l = 0; l < lanes; ++l) {
         if (l > 0 && !lane[l]) {
             if (gpbo_create(ctx->device, &lane[l]) != GPBO_OK) {
                 ctx->err = "lml_batch: could not create a work context";
-                cleanup();
+                ctx->lookahead = true;
                 return GPBO_ERR_HIP;
             }
             ctx->lml_lanes.push_back(lane[l]);
@@ -1359,11 +1401,11 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         int st = ensure_model(c, n_pad, d, true);
         if (st != GPBO_OK) {
             if (l > 0) ctx->err = c->err;
-            cleanup();
+            ctx->lookahead = true;
             return st;
         }
-        c->lookahead = (lanes == 1);   // several lanes already overlap each other's panel work
-        c->fitted = false;             // the model buffers are work space here
+        c->lookahead = (lanes == 1) && !use_graph;   // several lanes already overlap each other's panel work
+        c->fitted = false;                           // the model buffers are work space here
         c->have_posterior = false;
         c->have_factor = false;
         c->inc_valid = false;
@@ -1373,69 +1415,114 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         c->d = d;
         c->kernel = kernel;
         c->variant = GPBO_VARIANT_SINGLE;
-        if (grad_out) LCHK(hipMalloc((void**)&gpart[l], (size_t)ntiles * GRAD_D * 8));
+        if (!c->lane_slot) LCHK(hipMalloc((void**)&c->lane_slot, sizeof(LmlSlot)));
+        if (grad_out && c->lane_gpart_cap < (size_t)ntiles * GRAD_D) {
+            if (c->lane_gpart) hipFree(c->lane_gpart);
+            c->lane_gpart = nullptr;
+            c->lane_gpart_cap = 0;
+            LCHK(hipMalloc((void**)&c->lane_gpart, (size_t)ntiles * GRAD_D * 8));
+            c->lane_gpart_cap = (size_t)ntiles * GRAD_D;
+        }
     }
-    LCHK(hipMalloc((void**)&Xraw, (size_t)d * n_pad * 8));
-    LCHK(hipMalloc((void**)&th_dev, (size_t)B * d * 8));
-    LCHK(hipMalloc((void**)&onll, (size_t)B * 8));
-    LCHK(hipMalloc((void**)&ograd, (size_t)B * d * 8));
-    LCHK(hipMalloc((void**)&infos, (size_t)B * sizeof(int)));
     {
         std::vector<double> xr((size_t)d * n_pad, 0.0), yp(n_pad, 0.0);
         for (int t = 0; t < d; ++t)
             for (int64_t i = 0; i < n; ++i) xr[(size_t)t * n_pad + i] = X[i * d + t];
         for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
-        LCHK(hipMemcpy(Xraw, xr.data(), xr.size() * 8, hipMemcpyHostToDevice));
+        LCHK(hipMemcpy(ctx->lb_xraw, xr.data(), xr.size() * 8, hipMemcpyHostToDevice));
         for (int l = 0; l < lanes; ++l) LCHK(hipMemcpy(lane[l]->yv, yp.data(), yp.size() * 8, hipMemcpyHostToDevice));
-        LCHK(hipMemcpy(th_dev, thetas, (size_t)B * d * 8, hipMemcpyHostToDevice));
-        LCHK(hipMemset(infos, 0, (size_t)B * sizeof(int)));
+        LCHK(hipMemcpy(ctx->lb_th, thetas, (size_t)B * d * 8, hipMemcpyHostToDevice));
+        LCHK(hipMemcpy(ctx->lb_sg, sigmas, (size_t)B * 8, hipMemcpyHostToDevice));
         LCHK(hipDeviceSynchronize());
+    }
+    // the launch sequence of one setting on lane c; every argument is the same for every setting
+    auto enqueue_setting = [&](gpbo_ctx* c) -> int {
+        hipLaunchKernelGGL(k_setup_setting, dim3((unsigned)((n_pad + 255) / 256), (unsigned)d), dim3(256), 0, c->stream,
+                           (const double*)ctx->lb_xraw, (const double*)c->lane_slot->theta, (int)d, (int)n_pad, c->Xts, c->params);
+        int st = launch_kernel_matrix(c, c->bufA, nullptr, 0.0, &c->lane_slot->eps);
+        if (st == GPBO_OK) st = launch_cholesky(c, c->bufA, &c->lane_slot->info);
+        if (st == GPBO_OK) st = launch_trsv(c, c->bufA);
+        if (st != GPBO_OK) return st;
+        hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, c->stream, (const double*)c->bufA, (long)n_pad,
+                           (const double*)c->yv, (const double*)c->alpha1, c->alpha, (int)n, (int)n_pad,
+                           (int)GPBO_VARIANT_SINGLE, c->params);
+        if (grad_out) {
+            st = launch_inverse(c, c->bufA, c->bufW, c->bufB);
+            if (st != GPBO_OK) return st;
+            if (hipMemsetAsync(c->lane_gpart, 0, (size_t)ntiles * GRAD_D * 8, c->stream) != hipSuccess) return GPBO_ERR_HIP;
+            hipLaunchKernelGGL(k_lml_grad_tiles, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(GEMM_THREADS), 0, c->stream,
+                               (const double*)c->bufW, (long)n_pad, (const double*)c->Xts, (int)n, (int)n_pad, (int)d,
+                               (const double*)c->alpha1, (const double*)c->params, c->lane_gpart, nb, (int)kernel);
+        }
+        hipLaunchKernelGGL(k_lml_store, dim3(1), dim3(256), 0, c->stream, (const double*)c->params, (const LmlSlot*)c->lane_slot,
+                           (const double*)c->lane_gpart, ntiles, (int)d, grad_out ? 1 : 0, ctx->lb_nll, ctx->lb_grad, ctx->lb_info);
+        return GPBO_OK;
+    };
+    if (use_graph) {
+        const std::vector<int64_t> key = {n, n_pad, d, kernel, grad_out ? 1 : 0, (int64_t)(intptr_t)ctx->lb_xraw,
+                                          (int64_t)(intptr_t)ctx->lb_nll, (int64_t)(intptr_t)ctx->lb_grad,
+                                          (int64_t)(intptr_t)ctx->lb_info, 0};
+        for (int l = 0; l < lanes; ++l) {
+            gpbo_ctx* c = lane[l];
+            std::vector<int64_t> k = key;
+            k.back() = (int64_t)(intptr_t)c->lane_gpart;
+            if (c->lane_graph && c->lane_graph_key == k) continue;
+            if (c->lane_graph) {
+                hipGraphExecDestroy(c->lane_graph);
+                c->lane_graph = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            c->no_timing = true;
+            hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+            int st = GPBO_OK;
+            if (e == hipSuccess) {
+                st = enqueue_setting(c);
+                e = hipStreamEndCapture(c->stream, &g);
+            }
+            c->no_timing = false;
+            if (e == hipSuccess && st == GPBO_OK) e = hipGraphInstantiate(&c->lane_graph, g, nullptr, nullptr, 0);
+            if (g) hipGraphDestroy(g);
+            if (st != GPBO_OK) {
+                if (c != ctx) ctx->err = c->err;
+                ctx->lookahead = true;
+                return st;
+            }
+            if (e != hipSuccess) return fail_hip("lml_batch: graph capture", e);
+            c->lane_graph_key = k;
+        }
     }
     const auto t0 = std::chrono::steady_clock::now();
     for (int l = 0; l < lanes; ++l) timing_begin(lane[l]);
     for (int b = 0; b < B; ++b) {
         gpbo_ctx* c = lane[b % lanes];
-        const double eps = (sigmas[b] == 0) ? 1e-15 * (double)n : sigmas[b] * sigmas[b];
-        hipLaunchKernelGGL(k_setup_setting, dim3((unsigned)((n_pad + 255) / 256), (unsigned)d), dim3(256), 0, c->stream,
-                           (const double*)Xraw, (const double*)(th_dev + (size_t)b * d), (int)d, (int)n_pad, c->Xts, c->params);
-        int st = launch_kernel_matrix(c, c->bufA, nullptr, eps);
-        if (st == GPBO_OK) st = launch_cholesky(c, c->bufA, infos + b);
-        if (st == GPBO_OK) st = launch_trsv(c, c->bufA);
-        if (st == GPBO_OK) {
-            hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, c->stream, (const double*)c->bufA, (long)n_pad,
-                               (const double*)c->yv, (const double*)c->alpha1, c->alpha, (int)n, (int)n_pad,
-                               (int)GPBO_VARIANT_SINGLE, c->params);
-            if (grad_out) {
-                st = launch_inverse(c, c->bufA, c->bufW, c->bufB);
-                if (st == GPBO_OK) {
-                    hipMemsetAsync(gpart[b % lanes], 0, (size_t)ntiles * GRAD_D * 8, c->stream);
-                    hipLaunchKernelGGL(k_lml_grad_tiles, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(GEMM_THREADS), 0, c->stream, (const double*)c->bufW,
-                                       (long)n_pad, (const double*)c->Xts, (int)n, (int)n_pad, (int)d, (const double*)c->alpha1,
-                                       (const double*)c->params, gpart[b % lanes], nb, (int)kernel);
-                }
+        hipLaunchKernelGGL(k_pick_setting, dim3(1), dim3(64), 0, c->stream, b, (const double*)ctx->lb_th, (const double*)ctx->lb_sg,
+                           (int)d, (int)n, c->lane_slot);
+        if (use_graph) {
+            LCHK(hipGraphLaunch(c->lane_graph, c->stream));
+        } else {
+            const int st = enqueue_setting(c);
+            if (st != GPBO_OK) {
+                if (c != ctx) ctx->err = c->err;
+                for (int l = 0; l < lanes; ++l) hipStreamSynchronize(lane[l]->stream);
+                ctx->lookahead = true;
+                return st;
             }
-        }
-        if (st != GPBO_OK) {
-            if (c != ctx) ctx->err = c->err;
-            cleanup();
-            return st;
-        }
-        hipLaunchKernelGGL(k_lml_store, dim3(1), dim3(256), 0, c->stream, (const double*)c->params, (const int*)(infos + b),
-                           (const double*)gpart[b % lanes], ntiles, (int)d, grad_out ? 1 : 0, onll + b, ograd + (size_t)b * d);
-        // the event pool of a lane grows with every launch sequence; recycle it when the lane's stream is idle enough
-        if (c->pool_used > 4096) {
-            hipStreamSynchronize(c->stream);
-            timing_begin(c);
+            // the event pool of a lane grows with every launch sequence; recycle it when the lane's stream is idle enough
+            if (c->pool_used > 4096) {
+                hipStreamSynchronize(c->stream);
+                timing_begin(c);
+            }
         }
     }
     LCHK(hipGetLastError());
     for (int l = 0; l < lanes; ++l) LCHK(hipStreamSynchronize(lane[l]->stream));
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::vector<int> hinfo(B);
-    LCHK(hipMemcpy(nll_out, onll, (size_t)B * 8, hipMemcpyDeviceToHost));
-    if (grad_out) LCHK(hipMemcpy(grad_out, ograd, (size_t)B * d * 8, hipMemcpyDeviceToHost));
-    LCHK(hipMemcpy(hinfo.data(), infos, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    LCHK(hipMemcpy(nll_out, ctx->lb_nll, (size_t)B * 8, hipMemcpyDeviceToHost));
+    if (grad_out) LCHK(hipMemcpy(grad_out, ctx->lb_grad, (size_t)B * d * 8, hipMemcpyDeviceToHost));
+    LCHK(hipMemcpy(hinfo.data(), ctx->lb_info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
 #undef LCHK
+    ctx->lookahead = true;               // lane 0 is the caller's context
     ctx->tm.fit_total_ms = wall_ms;      // host wall time of the whole sweep (several streams run concurrently)
     ctx->tm.chol_count = B;
     ctx->tm.kbuild_ms = ctx->tm.chol_ms = ctx->tm.trsv_ms = ctx->tm.inverse_ms = 0;
@@ -1444,7 +1531,6 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         if (status_out) status_out[b] = bad ? GPBO_ERR_NOT_PD : GPBO_OK;
         if (bad) nll_out[b] = NAN;
     }
-    cleanup();
     return GPBO_OK;
 }
 

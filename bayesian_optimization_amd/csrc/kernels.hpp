@@ -45,14 +45,15 @@ __device__ __forceinline__ double kern_dfac(double D, int kernel) {
 
 // ---------------------------------------------------------------------------------------
 // K(X,X): full symmetric n_pad x n_pad matrix, scale*k(D) + eps on the diagonal, identity pad.
-// Xts is [d][n_pad] = X / theta.  scale_ptr == nullptr -> 1.
+// Xts is [d][n_pad] = X / theta.  scale_ptr == nullptr -> 1.  eps: eps_ptr[0] if eps_ptr, else eps_val.
 __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ Xts, int n, int n_pad, int d,
                                                        double* __restrict__ K, const double* __restrict__ scale_ptr,
-                                                       double eps, int kernel) {
+                                                       double eps_val, const double* __restrict__ eps_ptr, int kernel) {
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= n_pad || j >= n_pad) return;
     const double scale = scale_ptr ? *scale_ptr : 1.0;
+    const double eps = eps_ptr ? *eps_ptr : eps_val;      // from device memory when the launch is replayed from a graph
     double v;
     if (i == j) {
         v = (i < n) ? scale + eps : 1.0;
@@ -1187,14 +1188,41 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
     }
 }
 
-// out_nll[b] = -logL (NaN when the factorisation failed), out_grad[b*d + t] = -1/2 * sum_tiles gpart / theta_t
-__global__ __launch_bounds__(256) void k_lml_store(const double* __restrict__ params, const int* __restrict__ info,
+// Per-lane device slot of the likelihood sweep: everything that changes from one setting to the next reaches the
+// kernels through it, so the launch sequence of a setting has constant arguments and can be replayed from a graph.
+struct LmlSlot {
+    double theta[MAX_D];
+    double eps;
+    int cur;      // index of the setting in the batch
+    int info;     // factorisation status of this setting
+};
+
+__global__ void k_pick_setting(int b, const double* __restrict__ thetas, const double* __restrict__ sigmas, int d, int n,
+                               LmlSlot* __restrict__ slot) {
+    const int t = threadIdx.x;
+    if (t < d) slot->theta[t] = thetas[(long)b * d + t];
+    if (t == 0) {
+        const double sg = sigmas[b];
+        slot->eps = (sg == 0.0) ? 1e-15 * (double)n : sg * sg;
+        slot->cur = b;
+        slot->info = 0;
+    }
+}
+
+// b = slot->cur: out_nll[b] = -logL (NaN when the factorisation failed), out_grad[b*d + t] = -1/2 * sum_tiles gpart / theta_t,
+// out_info[b] = the factorisation status
+__global__ __launch_bounds__(256) void k_lml_store(const double* __restrict__ params, const LmlSlot* __restrict__ slot,
                                                    const double* __restrict__ gpart, int ntiles, int d, int want_grad,
-                                                   double* __restrict__ out_nll, double* __restrict__ out_grad) {
+                                                   double* __restrict__ out_nll, double* __restrict__ out_grad,
+                                                   int* __restrict__ out_info) {
     __shared__ double r[256];
     const int tid = threadIdx.x;
-    const bool bad = (*info != 0);
-    if (tid == 0) *out_nll = bad ? NAN : params[P_NLL];
+    const int b = slot->cur;
+    const bool bad = (slot->info != 0);
+    if (tid == 0) {
+        out_nll[b] = bad ? NAN : params[P_NLL];
+        out_info[b] = slot->info;
+    }
     if (!want_grad) return;
     for (int t = 0; t < d; ++t) {
         double s = 0.0;
@@ -1205,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_lml_store(const double* __restrict__ pa
             if (tid < o) r[tid] += r[tid + o];
             __syncthreads();
         }
-        if (tid == 0) out_grad[t] = bad ? NAN : -0.5 * r[0] * params[P_INVTHETA + t];
+        if (tid == 0) out_grad[(long)b * d + t] = bad ? NAN : -0.5 * r[0] * params[P_INVTHETA + t];
         __syncthreads();
     }
 }
