@@ -42,6 +42,7 @@ struct gpbo_ctx {
     // model
     bool fitted = false;
     int64_t n = 0, n_pad = 0, nb = 0, cap_pad = 0;
+    int cap_batch = 1;
     int d = 0, kernel = 0, variant = 0;
     double sigmaY = 0, eps = 0, theta1 = 0, nll = 0, y_max = 0;
     std::vector<double> theta;
@@ -75,7 +76,11 @@ struct gpbo_ctx {
     LmlSlot* lane_slot = nullptr;
     hipGraphExec_t lane_graph = nullptr;
     std::vector<int64_t> lane_graph_key;
+    size_t params_cap = PARAMS_DOUBLES, slot_cap = 0;
     bool no_timing = false;     // set while a launch sequence is captured into a graph
+    int batch = 1;              // > 1: a batched context, every model buffer holds `batch` slots (see BatchStride)
+    BatchStride bs;
+    gpbo_ctx* lml_lock = nullptr;   // the batched work context of the likelihood sweep (caller context only)
 
     // work contexts of the batched likelihood sweep (created on first use, kept for the next call)
     std::vector<gpbo_ctx*> lml_lanes;
@@ -194,27 +199,29 @@ void free_model(gpbo_ctx* ctx) {
 
 // (re)allocate model buffers for n_pad; full = also the factor buffers (fit ranks)
 int ensure_model(gpbo_ctx* ctx, int64_t n_pad, int d, bool full) {
-    const bool need = (n_pad != ctx->cap_pad) || (full && !ctx->bufA) || d > MAX_D;
+    const bool need = (n_pad != ctx->cap_pad) || (full && !ctx->bufA) || d > MAX_D || ctx->batch != ctx->cap_batch;
     if (d > MAX_D) BADARG("d exceeds 32");
     if (!need) return GPBO_OK;
     free_model(ctx);
-    const size_t nn = (size_t)n_pad * n_pad;
+    const size_t S = (size_t)ctx->batch;
+    const size_t nn = (size_t)n_pad * n_pad * S, nv = (size_t)n_pad * S;
     CHK(dev_alloc(ctx, &ctx->bufW, nn));
     if (full) {
         CHK(dev_alloc(ctx, &ctx->bufA, nn));
         CHK(dev_alloc(ctx, &ctx->bufB, nn));
-        CHK(dev_alloc(ctx, &ctx->Dinv, (size_t)n_pad * PB));
-        CHK(dev_alloc(ctx, &ctx->alpha1, n_pad));
-        CHK(dev_alloc(ctx, &ctx->yv, n_pad));
-        CHK(dev_alloc(ctx, &ctx->work, n_pad));
-        CHK(dev_alloc(ctx, &ctx->zv, n_pad));
-        CHK(dev_alloc(ctx, &ctx->zfw, n_pad));
-        CHK(dev_alloc(ctx, &ctx->kvec, n_pad));
-        CHK(dev_alloc(ctx, &ctx->lvec, n_pad));
+        CHK(dev_alloc(ctx, &ctx->Dinv, (size_t)n_pad * PB * S));
+        CHK(dev_alloc(ctx, &ctx->alpha1, nv));
+        CHK(dev_alloc(ctx, &ctx->yv, nv));
+        CHK(dev_alloc(ctx, &ctx->work, nv));
+        CHK(dev_alloc(ctx, &ctx->zv, nv));
+        CHK(dev_alloc(ctx, &ctx->zfw, nv));
+        CHK(dev_alloc(ctx, &ctx->kvec, nv));
+        CHK(dev_alloc(ctx, &ctx->lvec, nv));
     }
-    CHK(dev_alloc(ctx, &ctx->Xts, (size_t)MAX_D * n_pad));
-    CHK(dev_alloc(ctx, &ctx->alpha, n_pad));
+    CHK(dev_alloc(ctx, &ctx->Xts, (size_t)MAX_D * n_pad * S));
+    CHK(dev_alloc(ctx, &ctx->alpha, nv));
     ctx->cap_pad = n_pad;
+    ctx->cap_batch = ctx->batch;
     return GPBO_OK;
 }
 
@@ -245,9 +252,9 @@ int ensure_scratch(gpbo_ctx* ctx) {
 // ---------------------------------------------------------------- launch sequences
 int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, double eps, const double* eps_ptr = nullptr) {
     Scope s(ctx, T_KBUILD);
-    dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4));
+    dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4), (unsigned)ctx->batch);
     hipLaunchKernelGGL(k_kernel_matrix, grid, dim3(256), 0, ctx->stream, ctx->Xts, (int)ctx->n, (int)ctx->n_pad, ctx->d, K,
-                       scale_ptr, eps, eps_ptr, ctx->kernel);
+                       scale_ptr, eps, eps_ptr, ctx->kernel, ctx->bs);
     HIPCHK(hipGetLastError());
     return GPBO_OK;
 }
@@ -267,11 +274,14 @@ void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, 
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
     for (int q = p0; q < p0 + g; ++q) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev);
-        if (q + 1 < nb) hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1), dim3(GEMM_THREADS), 0, st, A, ld, q, ctx->Dinv);
+        const unsigned S = (unsigned)ctx->batch;
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs);
+        if (q + 1 < nb)
+            hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1, 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
         const int rest = p0 + g - 1 - q;      // the group's block columns right of q take panel q at once (K = 128):
         if (rest > 0)                         // more tiles per launch and a shorter chain than one growing-K update per column
-            hipLaunchKernelGGL(k_syrk_update<false>, dim3(rest, nb - q - 1), dim3(GEMM_THREADS), 0, st, A, ld, q + 1, q + 1, q * PB, PB);
+            hipLaunchKernelGGL(k_syrk_update<false>, dim3(rest, nb - q - 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q + 1, q + 1, q * PB, PB,
+                               ctx->bs);
     }
 }
 
@@ -333,14 +343,14 @@ int launch_cholesky_lookahead(gpbo_ctx* ctx, double* A, int* info_dev) {
         HIPCHK(hipEventRecord(ev, P));
         HIPCHK(hipStreamWaitEvent(B, ev, 0));
         const int gn = std::min(G, T);              // width of the next group
-        hipLaunchKernelGGL(k_syrk_update<false>, dim3(gn, T), dim3(GEMM_THREADS), 0, B, A, ld, c1, c1, p0 * PB, g * PB);
+        hipLaunchKernelGGL(k_syrk_update<false>, dim3(gn, T), dim3(GEMM_THREADS), 0, B, A, ld, c1, c1, p0 * PB, g * PB, ctx->bs);
         ev = sync_event(ctx, ne++);                 // U_next(g) done: the next group's columns are up to date
         HIPCHK(hipEventRecord(ev, B));
         HIPCHK(hipStreamWaitEvent(P, ev, 0));
         const int T2 = T - gn;
         if (T2 > 0)
             hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T2 * (T2 + 1) / 2)), dim3(GEMM_THREADS), 0, B, A, ld, c1 + gn,
-                               c1 + gn, p0 * PB, g * PB);
+                               c1 + gn, p0 * PB, g * PB, ctx->bs);
     }
     ev = sync_event(ctx, ne++);
     HIPCHK(hipEventRecord(ev, P));
@@ -363,7 +373,7 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     // wait took ~0.5 s and progress then stopped: with more user queues than hardware queue slots the scheduler
     // time-slices the queues, and a chain of waits between queues advances one slice at a time.
     bool la = false;
-    if (const char* e = getenv("GPBO_CHOL_LOOKAHEAD")) la = atoi(e) != 0 && ctx->lookahead && nb > 3 * G;
+    if (const char* e = getenv("GPBO_CHOL_LOOKAHEAD")) la = atoi(e) != 0 && ctx->lookahead && nb > 3 * G && ctx->batch == 1;
     if (la) {
         CHK(launch_cholesky_lookahead(ctx, A, info_dev));
     } else {
@@ -372,12 +382,12 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
             chol_factor_group(ctx->stream, ctx, A, info_dev, p0, g);
             const int T = nb - (p0 + g);
             if (T > 0)
-                hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T * (T + 1) / 2)), dim3(GEMM_THREADS), 0, ctx->stream, A, ld,
-                                   p0 + g, p0 + g, p0 * PB, g * PB);
+                hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
+                                   ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
         }
     }
-    dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4));
-    hipLaunchKernelGGL(k_zero_upper, grid, dim3(256), 0, ctx->stream, A, (int)ctx->n_pad);
+    dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4), (unsigned)ctx->batch);
+    hipLaunchKernelGGL(k_zero_upper, grid, dim3(256), 0, ctx->stream, A, (int)ctx->n_pad, ctx->bs);
     HIPCHK(hipGetLastError());
     return GPBO_OK;
 }
@@ -387,12 +397,16 @@ int launch_trsv(gpbo_ctx* ctx, const double* L) {
     Scope s(ctx, T_TRSV);
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
-    HIPCHK(hipMemcpyAsync(ctx->work, ctx->yv, ctx->n_pad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    const unsigned S = (unsigned)ctx->batch;
+    const size_t vbytes = (size_t)ctx->n_pad * S * sizeof(double);
+    HIPCHK(hipMemcpyAsync(ctx->work, ctx->yv, vbytes, hipMemcpyDeviceToDevice, ctx->stream));
     for (int p = 0; p < nb; ++p)
-        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nb - p), dim3(256), 0, ctx->stream, L, ld, ctx->Dinv, ctx->work, ctx->zv, p);
-    HIPCHK(hipMemcpyAsync(ctx->zfw, ctx->zv, ctx->n_pad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // z = L^-1 y
+        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nb - p, 1, S), dim3(256), 0, ctx->stream, L, ld, (const double*)ctx->Dinv, ctx->work,
+                           ctx->zv, p, ctx->bs);
+    HIPCHK(hipMemcpyAsync(ctx->zfw, ctx->zv, vbytes, hipMemcpyDeviceToDevice, ctx->stream));   // z = L^-1 y
     for (int p = nb - 1; p >= 0; --p)
-        hipLaunchKernelGGL(k_trsv_bwd_step, dim3(p + 1), dim3(256), 0, ctx->stream, L, ld, ctx->Dinv, ctx->zv, ctx->alpha1, p);
+        hipLaunchKernelGGL(k_trsv_bwd_step, dim3(p + 1, 1, S), dim3(256), 0, ctx->stream, L, ld, (const double*)ctx->Dinv, ctx->zv,
+                           ctx->alpha1, p, ctx->bs);
     HIPCHK(hipGetLastError());
     return GPBO_OK;
 }
@@ -402,13 +416,14 @@ int launch_inverse(gpbo_ctx* ctx, const double* L, double* W, double* T) {
     Scope s(ctx, T_INV);
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
-    HIPCHK(hipMemsetAsync(W, 0, (size_t)ctx->n_pad * ctx->n_pad * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(k_inv_copy_diag, dim3(nb), dim3(256), 0, ctx->stream, W, ld, ctx->Dinv);
+    const unsigned S = (unsigned)ctx->batch;
+    HIPCHK(hipMemsetAsync(W, 0, (size_t)ctx->n_pad * ctx->n_pad * S * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_inv_copy_diag, dim3(nb, 1, S), dim3(256), 0, ctx->stream, W, ld, (const double*)ctx->Dinv, ctx->bs);
     for (int sb = 1; sb < nb; sb *= 2) {
         const int pairs = (nb + 2 * sb - 1) / (2 * sb);
-        dim3 grid(sb, sb, pairs);      // step1: (ib, jb), step2: (jb, reversed ib): the slow index orders tiles longest first
-        hipLaunchKernelGGL(k_inv_step1, grid, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb);
-        hipLaunchKernelGGL(k_inv_step2, grid, dim3(GEMM_THREADS), 0, ctx->stream, W, (const double*)T, ld, sb, nb);
+        dim3 grid(sb, sb, pairs * S);  // step1: (ib, jb), step2: (jb, reversed ib): the slow index orders tiles longest first
+        hipLaunchKernelGGL(k_inv_step1, grid, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb, ctx->bs);
+        hipLaunchKernelGGL(k_inv_step2, grid, dim3(GEMM_THREADS), 0, ctx->stream, W, (const double*)T, ld, sb, nb, ctx->bs);
     }
     HIPCHK(hipGetLastError());
     return GPBO_OK;
@@ -696,6 +711,8 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (gpbo_ctx* l : ctx->lml_lanes) gpbo_destroy(l);
     ctx->lml_lanes.clear();
+    if (ctx->lml_lock) gpbo_destroy(ctx->lml_lock);
+    ctx->lml_lock = nullptr;
     free_model(ctx);
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
                   ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
@@ -779,7 +796,7 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
         nchol += 1;
         CHK(launch_trsv(ctx, ctx->bufA));
         hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bufA, (long)n_pad,
-                           (const double*)ctx->yv, (const double*)ctx->alpha1, ctx->alpha, (int)n, (int)n_pad, variant, ctx->params);
+                           (const double*)ctx->yv, (const double*)ctx->alpha1, ctx->alpha, (int)n, (int)n_pad, variant, ctx->params, ctx->bs);
         if (variant == GPBO_VARIANT_V4) {
             CHK(launch_kernel_matrix(ctx, ctx->bufB, ctx->params + P_THETA1, ctx->eps));   // theta1*K0 + eps, :146-147
             CHK(launch_cholesky(ctx, ctx->bufB, ctx->info_dev));
@@ -1344,8 +1361,42 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     // the runtime): the sequence of one setting is captured once per lane into a graph and replayed.
     bool use_graph = nb <= 16;
     if (const char* e = getenv("GPBO_LML_GRAPH")) use_graph = atoi(e) != 0;
+    // Up to 16 panels and at least two settings: ONE batched work context runs up to 64 settings in lockstep, every
+    // kernel of the sequence covering all of them (slot = blockIdx.z).  The chain of small launches that bounds a
+    // single factorisation at these sizes is then paid once per round instead of once per setting; streams mapped on
+    // a handful of hardware queues overlap only 2-3 settings.
+    bool lockstep = nb <= 16 && B >= 2;
+    if (const char* e = getenv("GPBO_LML_LOCKSTEP")) lockstep = atoi(e) != 0 && B >= 2;
+    int slots = 1;
+    if (lockstep) {
+        size_t free_b = 0, total_b = 0;
+        const double per_slot = 3.2 * 8.0 * (double)n_pad * (double)n_pad;
+        slots = std::min<int>(B, 64);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            slots = (int)std::max(1.0, std::min((double)slots, std::floor(0.4 * (double)free_b / per_slot)));
+        if (slots < 2) lockstep = false;
+    }
+    if (lockstep) {
+        lanes = 1;
+        use_graph = false;
+    }
     std::vector<gpbo_ctx*> lane(lanes, nullptr);
     lane[0] = ctx;
+    if (lockstep) {
+        if (!ctx->lml_lock && gpbo_create(ctx->device, &ctx->lml_lock) != GPBO_OK) {
+            ctx->err = "lml_batch: could not create the batched work context";
+            return GPBO_ERR_HIP;
+        }
+        lane[0] = ctx->lml_lock;
+        lane[0]->batch = slots;
+        lane[0]->bs.mat = (long)n_pad * n_pad;
+        lane[0]->bs.dinv = (long)n_pad * PB;
+        lane[0]->bs.xts = (long)MAX_D * n_pad;
+        lane[0]->bs.vec = (long)n_pad;
+        lane[0]->bs.par = PARAMS_DOUBLES;
+        lane[0]->bs.gp = (long)ntiles * GRAD_D;
+        lane[0]->bs.slot = (long)(sizeof(LmlSlot) / sizeof(double));
+    }
     for (int l = 1; l < lanes && l - 1 < (int)ctx->lml_lanes.size(); ++l) lane[l] = ctx->lml_lanes[l - 1];
     auto fail_hip = [&](const char* what, hipError_t e) {
         ctx->err = std::string(what) + ": " + hipGetErrorString(e);
@@ -1415,13 +1466,27 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         c->d = d;
         c->kernel = kernel;
         c->variant = GPBO_VARIANT_SINGLE;
-        if (!c->lane_slot) LCHK(hipMalloc((void**)&c->lane_slot, sizeof(LmlSlot)));
-        if (grad_out && c->lane_gpart_cap < (size_t)ntiles * GRAD_D) {
+        const size_t S = (size_t)c->batch;
+        if (c->slot_cap < S) {
+            if (c->lane_slot) hipFree(c->lane_slot);
+            c->lane_slot = nullptr;
+            c->slot_cap = 0;
+            LCHK(hipMalloc((void**)&c->lane_slot, S * sizeof(LmlSlot)));
+            c->slot_cap = S;
+        }
+        if (c->params_cap < S * PARAMS_DOUBLES) {
+            if (c->params) hipFree(c->params);
+            c->params = nullptr;
+            c->params_cap = 0;
+            LCHK(hipMalloc((void**)&c->params, S * PARAMS_DOUBLES * sizeof(double)));
+            c->params_cap = S * PARAMS_DOUBLES;
+        }
+        if (grad_out && c->lane_gpart_cap < (size_t)ntiles * GRAD_D * S) {
             if (c->lane_gpart) hipFree(c->lane_gpart);
             c->lane_gpart = nullptr;
             c->lane_gpart_cap = 0;
-            LCHK(hipMalloc((void**)&c->lane_gpart, (size_t)ntiles * GRAD_D * 8));
-            c->lane_gpart_cap = (size_t)ntiles * GRAD_D;
+            LCHK(hipMalloc((void**)&c->lane_gpart, (size_t)ntiles * GRAD_D * 8 * S));
+            c->lane_gpart_cap = (size_t)ntiles * GRAD_D * S;
         }
     }
     {
@@ -1430,32 +1495,35 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             for (int64_t i = 0; i < n; ++i) xr[(size_t)t * n_pad + i] = X[i * d + t];
         for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
         LCHK(hipMemcpy(ctx->lb_xraw, xr.data(), xr.size() * 8, hipMemcpyHostToDevice));
-        for (int l = 0; l < lanes; ++l) LCHK(hipMemcpy(lane[l]->yv, yp.data(), yp.size() * 8, hipMemcpyHostToDevice));
+        for (int l = 0; l < lanes; ++l)
+            for (int sidx = 0; sidx < lane[l]->batch; ++sidx)
+                LCHK(hipMemcpy(lane[l]->yv + (size_t)sidx * n_pad, yp.data(), yp.size() * 8, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(ctx->lb_th, thetas, (size_t)B * d * 8, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(ctx->lb_sg, sigmas, (size_t)B * 8, hipMemcpyHostToDevice));
         LCHK(hipDeviceSynchronize());
     }
-    // the launch sequence of one setting on lane c; every argument is the same for every setting
+    // the launch sequence of one setting per slot of context c; every argument is the same for every setting
     auto enqueue_setting = [&](gpbo_ctx* c) -> int {
-        hipLaunchKernelGGL(k_setup_setting, dim3((unsigned)((n_pad + 255) / 256), (unsigned)d), dim3(256), 0, c->stream,
-                           (const double*)ctx->lb_xraw, (const double*)c->lane_slot->theta, (int)d, (int)n_pad, c->Xts, c->params);
+        const unsigned S = (unsigned)c->batch;
+        hipLaunchKernelGGL(k_setup_setting, dim3((unsigned)((n_pad + 255) / 256), (unsigned)d, S), dim3(256), 0, c->stream,
+                           (const double*)ctx->lb_xraw, (const double*)c->lane_slot->theta, (int)d, (int)n_pad, c->Xts, c->params, c->bs);
         int st = launch_kernel_matrix(c, c->bufA, nullptr, 0.0, &c->lane_slot->eps);
         if (st == GPBO_OK) st = launch_cholesky(c, c->bufA, &c->lane_slot->info);
         if (st == GPBO_OK) st = launch_trsv(c, c->bufA);
         if (st != GPBO_OK) return st;
-        hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, c->stream, (const double*)c->bufA, (long)n_pad,
+        hipLaunchKernelGGL(k_fit_scalars, dim3(1, 1, S), dim3(256), 0, c->stream, (const double*)c->bufA, (long)n_pad,
                            (const double*)c->yv, (const double*)c->alpha1, c->alpha, (int)n, (int)n_pad,
-                           (int)GPBO_VARIANT_SINGLE, c->params);
+                           (int)GPBO_VARIANT_SINGLE, c->params, c->bs);
         if (grad_out) {
             st = launch_inverse(c, c->bufA, c->bufW, c->bufB);
             if (st != GPBO_OK) return st;
-            if (hipMemsetAsync(c->lane_gpart, 0, (size_t)ntiles * GRAD_D * 8, c->stream) != hipSuccess) return GPBO_ERR_HIP;
-            hipLaunchKernelGGL(k_lml_grad_tiles, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(GEMM_THREADS), 0, c->stream,
+            if (hipMemsetAsync(c->lane_gpart, 0, (size_t)ntiles * GRAD_D * 8 * S, c->stream) != hipSuccess) return GPBO_ERR_HIP;
+            hipLaunchKernelGGL(k_lml_grad_tiles, dim3((unsigned)(nb * (nb + 1) / 2), 1, S), dim3(GEMM_THREADS), 0, c->stream,
                                (const double*)c->bufW, (long)n_pad, (const double*)c->Xts, (int)n, (int)n_pad, (int)d,
-                               (const double*)c->alpha1, (const double*)c->params, c->lane_gpart, nb, (int)kernel);
+                               (const double*)c->alpha1, (const double*)c->params, c->lane_gpart, nb, (int)kernel, c->bs);
         }
-        hipLaunchKernelGGL(k_lml_store, dim3(1), dim3(256), 0, c->stream, (const double*)c->params, (const LmlSlot*)c->lane_slot,
-                           (const double*)c->lane_gpart, ntiles, (int)d, grad_out ? 1 : 0, ctx->lb_nll, ctx->lb_grad, ctx->lb_info);
+        hipLaunchKernelGGL(k_lml_store, dim3(1, 1, S), dim3(256), 0, c->stream, (const double*)c->params, (const LmlSlot*)c->lane_slot,
+                           (const double*)c->lane_gpart, ntiles, (int)d, grad_out ? 1 : 0, ctx->lb_nll, ctx->lb_grad, ctx->lb_info, c->bs);
         return GPBO_OK;
     };
     if (use_graph) {
@@ -1493,10 +1561,10 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     }
     const auto t0 = std::chrono::steady_clock::now();
     for (int l = 0; l < lanes; ++l) timing_begin(lane[l]);
-    for (int b = 0; b < B; ++b) {
-        gpbo_ctx* c = lane[b % lanes];
-        hipLaunchKernelGGL(k_pick_setting, dim3(1), dim3(64), 0, c->stream, b, (const double*)ctx->lb_th, (const double*)ctx->lb_sg,
-                           (int)d, (int)n, c->lane_slot);
+    for (int b = 0, r = 0; b < B; b += lane[r % lanes]->batch, ++r) {
+        gpbo_ctx* c = lane[r % lanes];
+        hipLaunchKernelGGL(k_pick_setting, dim3((unsigned)c->batch), dim3(64), 0, c->stream, b, (int)B, (const double*)ctx->lb_th,
+                           (const double*)ctx->lb_sg, (int)d, (int)n, c->lane_slot);
         if (use_graph) {
             LCHK(hipGraphLaunch(c->lane_graph, c->stream));
         } else {

@@ -16,6 +16,19 @@ constexpr int PB = 128;    // Cholesky panel / diagonal block
 enum { P_THETA1 = 0, P_CB = 1, P_C0 = 2, P_C1 = 3, P_NLL = 4, P_YA = 5, P_SUMLOG = 6, P_YMAX = 7, P_INVTHETA = 8,
        P_BETA = 40, P_NBETA = 52, P_DEG = 53, P_CLAMP = 54 };
 constexpr int PARAMS_DOUBLES = 64;
+
+// A batched context holds S problems of the same shape side by side ("slots": every buffer is S times as long) and
+// runs them in lockstep: the kernels of the fit take the slot from blockIdx.z and move their pointers by these element
+// strides.  All zero (and gridDim.z = 1) for an ordinary context.
+struct BatchStride {
+    long mat = 0;    // n_pad * n_pad        (K / L, the scratch matrix, W)
+    long dinv = 0;   // n_pad * 128          (inverted diagonal blocks)
+    long xts = 0;    // MAX_D * n_pad        (scaled inputs)
+    long vec = 0;    // n_pad                (alpha, y, work vectors)
+    long par = 0;    // PARAMS_DOUBLES
+    long gp = 0;     // gradient tile partials
+    long slot = 0;   // sizeof(LmlSlot) / 8  (per-slot setting record, addressed as doubles)
+};
 constexpr int MAX_TREND = 10;
 constexpr int MAX_D = 32;
 
@@ -48,7 +61,12 @@ __device__ __forceinline__ double kern_dfac(double D, int kernel) {
 // Xts is [d][n_pad] = X / theta.  scale_ptr == nullptr -> 1.  eps: eps_ptr[0] if eps_ptr, else eps_val.
 __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ Xts, int n, int n_pad, int d,
                                                        double* __restrict__ K, const double* __restrict__ scale_ptr,
-                                                       double eps_val, const double* __restrict__ eps_ptr, int kernel) {
+                                                       double eps_val, const double* __restrict__ eps_ptr, int kernel,
+                                                       BatchStride bs) {
+    Xts += blockIdx.z * bs.xts;
+    K += blockIdx.z * bs.mat;
+    if (scale_ptr) scale_ptr += blockIdx.z * bs.par;
+    if (eps_ptr) eps_ptr += blockIdx.z * bs.slot;
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= n_pad || j >= n_pad) return;
@@ -446,15 +464,17 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
 // The LDS request (packed L + the product buffer of the inverse, 99 KB) keeps every tile-engine workgroup (72 KB of
 // 160) off the CU: the kernel is latency bound and runs 4x slower when its waves share SIMDs with MFMA waves.
 __global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
-                                                              double* __restrict__ Dinv, int* __restrict__ info) {
+                                                              double* __restrict__ Dinv, int* __restrict__ info, BatchStride bs) {
     __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES];
-    potrf_diag_body(A, ld, p, Dinv, info, S);
+    potrf_diag_body(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S);
 }
 
 // Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_panel(double* __restrict__ A, long ld, int p,
-                                                             const double* __restrict__ Dinv) {
+                                                             const double* __restrict__ Dinv, BatchStride bs) {
     __shared__ double lds[GEMM_LDS_DOUBLES];
+    A += blockIdx.z * bs.mat;
+    Dinv += blockIdx.z * bs.dinv;
     __builtin_amdgcn_s_setprio(2);
     const int ib = p + 1 + blockIdx.x;
     double* Ap = A + (long)ib * PB * ld + (long)p * PB;
@@ -477,7 +497,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_panel(double* __restri
 // !TRI: a rectangle of blocks, ib = b0 + blockIdx.y, jb = jb0 + blockIdx.x (every tile is computed).
 template <bool TRI>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restrict__ A, long ld, int b0, int jb0, int kcol0,
-                                                              int klen) {
+                                                              int klen, BatchStride bs) {
+    A += blockIdx.z * bs.mat;
     int ib, jb;
     if (TRI) {
         int i, j;
@@ -508,7 +529,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restr
 }
 
 // Zero the strict upper triangle (the factorisation leaves stale values there).
-__global__ __launch_bounds__(256) void k_zero_upper(double* __restrict__ A, int n_pad) {
+__global__ __launch_bounds__(256) void k_zero_upper(double* __restrict__ A, int n_pad, BatchStride bs) {
+    A += blockIdx.z * bs.mat;
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i < n_pad && j < n_pad && j > i) A[(long)i * n_pad + j] = 0.0;
@@ -518,7 +540,10 @@ __global__ __launch_bounds__(256) void k_zero_upper(double* __restrict__ A, int 
 // Triangular inverse W = inv(L) by recursive doubling over 128-blocks.
 // Level with half-size sb (in blocks); pair q joins A = blocks [a0, a0+sb) and
 // B = blocks [b0, b0+rows) below it:  W[B,A] = -inv(L_BB) * L[B,A] * inv(L_AA).
-__global__ __launch_bounds__(256) void k_inv_copy_diag(double* __restrict__ W, long ld, const double* __restrict__ Dinv) {
+__global__ __launch_bounds__(256) void k_inv_copy_diag(double* __restrict__ W, long ld, const double* __restrict__ Dinv,
+                                                       BatchStride bs) {
+    W += blockIdx.z * bs.mat;
+    Dinv += blockIdx.z * bs.dinv;
     const int p = blockIdx.x;
     double* blk = W + (long)p * PB * ld + (long)p * PB;
     const double* src = Dinv + (long)p * PB * PB;
@@ -527,8 +552,12 @@ __global__ __launch_bounds__(256) void k_inv_copy_diag(double* __restrict__ W, l
 
 // step 1: T[B,A] = L[B,A] * W[A,A]      (W[A,A] lower triangular: k >= j)
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __restrict__ L, const double* __restrict__ W,
-                                                            double* __restrict__ T, long ld, int sb, int nb) {
-    const int q = blockIdx.z;
+                                                            double* __restrict__ T, long ld, int sb, int nb, BatchStride bs) {
+    const int pairs = (nb + 2 * sb - 1) / (2 * sb);      // gridDim.z = pairs * slots
+    const int q = blockIdx.z % pairs, slot = blockIdx.z / pairs;
+    L += slot * bs.mat;
+    W += slot * bs.mat;
+    T += slot * bs.mat;
     const int a0 = 2 * q * sb, b0 = a0 + sb;
     const int rows = min(sb, nb - b0);
     const int ib = blockIdx.x, jb = blockIdx.y;      // jb slow: the long tiles (small jb) are dispatched first
@@ -550,8 +579,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __r
 
 // step 2: W[B,A] = - W[B,B] * T[B,A]    (W[B,B] lower triangular: k <= i)
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restrict__ W, const double* __restrict__ T, long ld,
-                                                            int sb, int nb) {
-    const int q = blockIdx.z;
+                                                            int sb, int nb, BatchStride bs) {
+    const int pairs = (nb + 2 * sb - 1) / (2 * sb);
+    const int q = blockIdx.z % pairs, slot = blockIdx.z / pairs;
+    W += slot * bs.mat;
+    T += slot * bs.mat;
     const int a0 = 2 * q * sb, b0 = a0 + sb;
     const int rows = min(sb, nb - b0);
     const int ib = rows - 1 - (int)blockIdx.y, jb = blockIdx.x;      // long tiles (large ib) first
@@ -576,8 +608,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
 // Forward step p: z_p = inv(L_pp) w_p ; w_ib -= L[ib,p] z_p for ib > p.   grid = nb - p.
 __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, long ld,
                                                        const double* __restrict__ Dinv, double* __restrict__ w,
-                                                       double* __restrict__ z, int p) {
+                                                       double* __restrict__ z, int p, BatchStride bs) {
     __shared__ double yp[PB];
+    L += blockIdx.z * bs.mat;
+    Dinv += blockIdx.z * bs.dinv;
+    w += blockIdx.z * bs.vec;
+    z += blockIdx.z * bs.vec;
     __shared__ double zp[PB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < PB) yp[tid] = w[p * PB + tid];
@@ -623,8 +659,12 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict_
 // Backward step p (L^T x = z): x_p = inv(L_pp)^T z_p ; z_jb -= L[p,jb]^T x_p for jb < p.  grid = p + 1.
 __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, long ld,
                                                        const double* __restrict__ Dinv, double* __restrict__ z,
-                                                       double* __restrict__ x, int p) {
+                                                       double* __restrict__ x, int p, BatchStride bs) {
     __shared__ double zp[PB];
+    L += blockIdx.z * bs.mat;
+    Dinv += blockIdx.z * bs.dinv;
+    z += blockIdx.z * bs.vec;
+    x += blockIdx.z * bs.vec;
     __shared__ double xp[PB];
     __shared__ double red[256];
     const int tid = threadIdx.x;
@@ -659,8 +699,14 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
 // One workgroup (deterministic order).
 __global__ __launch_bounds__(256) void k_fit_scalars(const double* __restrict__ L, long ld, const double* __restrict__ y,
                                                      const double* __restrict__ alpha1, double* __restrict__ alpha_out,
-                                                     int n, int n_pad, int variant, double* __restrict__ params) {
+                                                     int n, int n_pad, int variant, double* __restrict__ params,
+                                                     BatchStride bs) {
     __shared__ double r1[256];
+    L += blockIdx.z * bs.mat;
+    y += blockIdx.z * bs.vec;
+    alpha1 += blockIdx.z * bs.vec;
+    alpha_out += blockIdx.z * bs.vec;
+    params += blockIdx.z * bs.par;
     __shared__ double r2[256];
     __shared__ double r3[256];
     const int tid = threadIdx.x;
@@ -933,7 +979,11 @@ __global__ __launch_bounds__(256) void k_acquire(const double* __restrict__ mu, 
 // Batched likelihood sweep helpers.
 // Per setting: Xts[t][i] = Xraw[t][i] / theta[t], params[P_INVTHETA + t] = 1 / theta[t].
 __global__ __launch_bounds__(256) void k_setup_setting(const double* __restrict__ Xraw, const double* __restrict__ theta,
-                                                       int d, int n_pad, double* __restrict__ Xts, double* __restrict__ params) {
+                                                       int d, int n_pad, double* __restrict__ Xts, double* __restrict__ params,
+                                                       BatchStride bs) {
+    theta += blockIdx.z * bs.slot;
+    Xts += blockIdx.z * bs.xts;
+    params += blockIdx.z * bs.par;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int t = blockIdx.y;
     const double it = 1.0 / theta[t];
@@ -952,7 +1002,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
                                                                     const double* __restrict__ Xts, int n, int n_pad, int d,
                                                                     const double* __restrict__ alpha1,
                                                                     const double* __restrict__ params,
-                                                                    double* __restrict__ gpart, int nb, int kernel) {
+                                                                    double* __restrict__ gpart, int nb, int kernel, BatchStride bs) {
+    W += blockIdx.z * bs.mat;
+    Xts += blockIdx.z * bs.xts;
+    alpha1 += blockIdx.z * bs.vec;
+    params += blockIdx.z * bs.par;
+    gpart += blockIdx.z * bs.gp;
     int jb, kb;                    // 1-D grid over the lower tiles; jb ascending = longest contraction first
     tri_decode(blockIdx.x, jb, kb);
     __shared__ double lds[GEMM_LDS_DOUBLES];
@@ -1196,15 +1251,21 @@ struct LmlSlot {
     int cur;      // index of the setting in the batch
     int info;     // factorisation status of this setting
 };
+static_assert(sizeof(LmlSlot) % sizeof(double) == 0, "slots are strided in doubles");
 
-__global__ void k_pick_setting(int b, const double* __restrict__ thetas, const double* __restrict__ sigmas, int d, int n,
-                               LmlSlot* __restrict__ slot) {
+__global__ void k_pick_setting(int b0, int B, const double* __restrict__ thetas, const double* __restrict__ sigmas, int d, int n,
+                               LmlSlot* __restrict__ slots) {
+    // slot blockIdx.x takes setting b0 + blockIdx.x; past the end of the batch it recomputes the last setting and is
+    // marked inactive (cur = -1: nothing is stored for it)
+    LmlSlot* slot = slots + blockIdx.x;
+    const int bq = b0 + blockIdx.x;
+    const int b = bq < B ? bq : B - 1;
     const int t = threadIdx.x;
     if (t < d) slot->theta[t] = thetas[(long)b * d + t];
     if (t == 0) {
         const double sg = sigmas[b];
         slot->eps = (sg == 0.0) ? 1e-15 * (double)n : sg * sg;
-        slot->cur = b;
+        slot->cur = bq < B ? bq : -1;
         slot->info = 0;
     }
 }
@@ -1214,10 +1275,14 @@ __global__ void k_pick_setting(int b, const double* __restrict__ thetas, const d
 __global__ __launch_bounds__(256) void k_lml_store(const double* __restrict__ params, const LmlSlot* __restrict__ slot,
                                                    const double* __restrict__ gpart, int ntiles, int d, int want_grad,
                                                    double* __restrict__ out_nll, double* __restrict__ out_grad,
-                                                   int* __restrict__ out_info) {
+                                                   int* __restrict__ out_info, BatchStride bs) {
     __shared__ double r[256];
+    params += blockIdx.z * bs.par;
+    slot += blockIdx.z;
+    gpart += blockIdx.z * bs.gp;
     const int tid = threadIdx.x;
     const int b = slot->cur;
+    if (b < 0) return;
     const bool bad = (slot->info != 0);
     if (tid == 0) {
         out_nll[b] = bad ? NAN : params[P_NLL];

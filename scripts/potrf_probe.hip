@@ -17,7 +17,7 @@ int main() {
         { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0);
-        k_potrf_diag<<<1, POTRF_THREADS>>>(dA, n, 0, dinv, info);
+        k_potrf_diag<<<1, POTRF_THREADS>>>(dA, n, 0, dinv, info, BatchStride{});
         (void)hipEventRecord(e1);
         (void)hipDeviceSynchronize();
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);

@@ -69,7 +69,7 @@ int main() {
             report("2-D square grid", T, klen, ms);
             for (int rep = 0; rep < 2; ++rep) {
                 (void)hipEventRecord(e0);
-                k_syrk_update<true><<<dim3(T * (T + 1) / 2), GEMM_THREADS>>>(A, ld, ib0, ib0, 0, klen);
+                k_syrk_update<true><<<dim3(T * (T + 1) / 2), GEMM_THREADS>>>(A, ld, ib0, ib0, 0, klen, BatchStride{});
                 (void)hipEventRecord(e1); (void)hipDeviceSynchronize(); (void)hipEventElapsedTime(&ms, e0, e1);
             }
             report("1-D lower tiles (library)", T, klen, ms);

@@ -371,7 +371,7 @@ def test_small_n_fused_likelihood_equals_the_general_path(gp0):
             ok += 1
         assert (stat[b] == 1) == bool(np.isnan(nll[b]))
     assert ok >= B // 2
-    # the general path, in a child process (the switch is read from the environment)
+    # the general paths, in child processes (the switches are read from the environment)
     code = ('import json,sys,numpy as np; sys.path.insert(0, %r); from bayesian_optimization_amd import GP; '
             'z=np.load(sys.argv[1]); g=GP(0); r=g.lml_batch(z["X"],z["y"],z["th"],z["sg"],grad=True); '
             'np.savez(sys.argv[2], nll=r[0], grad=r[1], stat=r[2])' % ROOT)
@@ -379,12 +379,14 @@ def test_small_n_fused_likelihood_equals_the_general_path(gp0):
     os.makedirs(tmp, exist_ok=True)
     fin, fout = os.path.join(tmp, 'small_in.npz'), os.path.join(tmp, 'small_out.npz')
     np.savez(fin, X=X, y=y, th=thetas, sg=sigmas)
-    subprocess.run([sys.executable, '-c', code, fin, fout], env=dict(os.environ, GPBO_LML_SMALL='0'), check=True, timeout=120)
-    z = np.load(fout)
-    good = (stat == 0) & (z['stat'] == 0) & ((sigmas > 0) | (thetas.max(1) <= 0.2))
-    assert good.sum() >= B // 2
-    assert np.max(np.abs(nll[good] - z['nll'][good]) / np.maximum(1.0, np.abs(nll[good]))) <= 1e-9
-    assert np.max(np.abs(grad[good] - z['grad'][good])) <= 1e-7 * max(1.0, np.max(np.abs(grad[good])))
+    # lockstep batched context, stream lanes with graph replay, stream lanes with plain launches
+    for extra in ({}, {'GPBO_LML_LOCKSTEP': '0'}, {'GPBO_LML_LOCKSTEP': '0', 'GPBO_LML_GRAPH': '0'}):
+        subprocess.run([sys.executable, '-c', code, fin, fout], env=dict(os.environ, GPBO_LML_SMALL='0', **extra), check=True, timeout=120)
+        z = np.load(fout)
+        good = (stat == 0) & (z['stat'] == 0) & ((sigmas > 0) | (thetas.max(1) <= 0.2))
+        assert good.sum() >= B // 2
+        assert np.max(np.abs(nll[good] - z['nll'][good]) / np.maximum(1.0, np.abs(nll[good]))) <= 1e-9
+        assert np.max(np.abs(grad[good] - z['grad'][good])) <= 1e-7 * max(1.0, np.max(np.abs(grad[good])))
 
 
 @pytest.mark.parametrize('n', [60, 300])
