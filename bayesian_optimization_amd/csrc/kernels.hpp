@@ -107,12 +107,16 @@ __device__ __forceinline__ constexpr int tri_off(int r) { return r * (r + 1) / 2
 constexpr int POTRF_LDS_PACKED = PB * (PB + 1) / 2;     // 8256 doubles
 // Factor phase on register tiles.  vec: [2][PB] LDS, dg: [PB] LDS (receives diag L).  Returns the first failing
 // column (pivot <= 0 or NaN) or -1.  All 256 threads must call it; it ends without a barrier after the last step.
-__device__ __forceinline__ int potrf_factor_regs(double (&a)[8][8], double* __restrict__ vec, double* __restrict__ dg) {
+// nt: number of leading 8-column tile columns to eliminate; the rest of the block must be the identity pad (rows and
+// columns >= 8 nt zero off the diagonal, one on it), which elimination leaves as it is.
+__device__ __forceinline__ int potrf_factor_regs(double (&a)[8][8], double* __restrict__ vec, double* __restrict__ dg,
+                                                 int nt = 16) {
     const int tid = threadIdx.x;
     const int tr = tid >> 4, tc = tid & 15;
     const bool lower = tr >= tc;
     int fail = -1;
-    for (int jt = 0; jt < 16; ++jt) {
+    if (tid < PB && tid >= nt * 8) dg[tid] = 1.0;      // beyond nt tile columns the block is the identity pad
+    for (int jt = 0; jt < nt; ++jt) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = jt * 8 + jj;
@@ -158,7 +162,7 @@ __device__ __forceinline__ int potrf_factor_regs(double (&a)[8][8], double* __re
 // LDS copy S, diag L from dg.  Step j: row j of X (scaled by 1/d_j) is final and published; rows r > j subtract
 // L[r][j] * X[j][:].  The caller has written S and dg and passed a barrier.
 __device__ __forceinline__ void potrf_inverse_regs(double (&a)[8][8], const double* __restrict__ S, double* __restrict__ vec,
-                                                   const double* __restrict__ dg) {
+                                                   const double* __restrict__ dg, int nt = 16) {
     const int tid = threadIdx.x;
     const int tr = tid >> 4, tc = tid & 15;
     const bool lower = tr >= tc;
@@ -166,7 +170,7 @@ __device__ __forceinline__ void potrf_inverse_regs(double (&a)[8][8], const doub
     for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) a[rr][cc] = (tr == tc && rr == cc) ? 1.0 : 0.0;   // X = I
-    for (int jt = 0; jt < 16; ++jt) {
+    for (int jt = 0; jt < nt; ++jt) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = jt * 8 + jj;
@@ -1133,7 +1137,8 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
             }
             a[rr][cc] = v;
         }
-    const int fail = potrf_factor_regs(a, vec, dg);
+    const int nt = (n + 7) >> 3;               // tile columns that hold data; the rest of the block is the identity pad
+    const int fail = potrf_factor_regs(a, vec, dg, nt);
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
@@ -1142,7 +1147,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
             if (c <= r) Wl[tri_off(r) + c] = a[rr][cc];
         }
     __syncthreads();
-    potrf_inverse_regs(a, Wl, vec, dg);
+    potrf_inverse_regs(a, Wl, vec, dg, nt);
     __syncthreads();                           // every read of the packed L is done
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr)
@@ -1154,13 +1159,13 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
     __syncthreads();
     if (tid < PB) {                            // z = W y (row tid)
         double z = 0.0;
-        for (int c = 0; c <= tid; ++c) z = fma(Wl[tid * SMALL_WP + c], yv[c], z);
+        for (int c = 0; c <= min(tid, nt * 8 - 1); ++c) z = fma(Wl[tid * SMALL_WP + c], yv[c], z);      // y is zero in the pad
         zv[tid] = z;
     }
     __syncthreads();
     if (tid < PB) {                            // alpha = W^T z (column tid)
         double s = 0.0;
-        for (int r = tid; r < PB; ++r) s = fma(Wl[r * SMALL_WP + tid], zv[r], s);
+        for (int r = tid; r < nt * 8; ++r) s = fma(Wl[r * SMALL_WP + tid], zv[r], s);                   // z is zero in the pad
         al[tid] = s;
         r1[tid] = yv[tid] * s;
         r2[tid] = (tid < n) ? log(dg[tid]) : 0.0;
@@ -1193,8 +1198,8 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
     for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) a[rr][cc] = 0.0;
-    if (lower) {
-        for (int r = tr * 8; r < PB; ++r) {
+    if (lower && tr < nt) {                    // pad rows of W are rows of the identity: they add nothing for j, k < n
+        for (int r = tr * 8; r < nt * 8; ++r) {
             double wj[8], wk[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
