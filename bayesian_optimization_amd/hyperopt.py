@@ -6,10 +6,10 @@ hypopt / hypopt_wrap (:167-186), with two changes: the gradient is the analytic 
 evaluated by gpbo_lml_batch instead of autograd's reverse pass, and all nruns starts advance together, one batched
 -logL + gradient call per iteration (the starts are the batch axis of the likelihood sweep).
 
-Supported step rules: 'diminishing' and the constant step (any other string, as in the reference where 'normal' /
-'standard' fall through to the else branch).  'backtrack' is not implemented (data-dependent inner loops per start).
-A start whose K stops being positive definite is frozen with cost +inf (the reference would raise LinAlgError out of
-the whole multi-start loop).
+Step rules: 'diminishing', 'backtrack' (the reference's own variant of the sufficient-decrease test, restated literally:
+:62-71) and the constant step (any other string, as in the reference where 'normal' / 'standard' fall through to the else
+branch).  A start whose K stops being positive definite is frozen with cost +inf (the reference would raise LinAlgError
+out of the whole multi-start loop).
 """
 from __future__ import annotations
 
@@ -30,7 +30,7 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
     """All rows of W0 (nruns, d) advance in lockstep.  Returns (weight_history, cost_history, exitflag):
     weight_history[r] is the list of iterates of start r, cost_history[r] the -logL at each of them."""
     if steprule == 'backtrack':
-        raise NotImplementedError("steprule 'backtrack' is not available in the batched optimiser")
+        return _backtrack_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, max_its, W0, device, kernel)
     gp = _lml_gp(device)
     W = np.array(W0, dtype=np.float64, copy=True)
     nruns, d = W.shape
@@ -74,6 +74,87 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
             w_hist[r].append(W[r].copy())
             c_hist[r].append(cost[r])
             if moved[r] < tol:
+                exitflag[r] = 1
+                active[r] = False
+        k += 1
+    return w_hist, c_hist, exitflag
+
+
+def _step_direction(norm, grad, dtemp, beta, d):
+    if norm == 'component':
+        return (1 - beta) * dtemp + beta * np.sign(grad) * np.sqrt(d)
+    if norm == 'full':
+        return (1 - beta) * dtemp + beta * grad / np.linalg.norm(grad, axis=1, keepdims=True)
+    return (1 - beta) * dtemp + beta * grad
+
+
+def _backtrack_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, max_its, W0, device, kernel, max_inner=200):
+    """steprule == 'backtrack' (BayesOpt_v4.ipynb:62-71), every start in lockstep.  Per outer iteration and start:
+        wtemp = w ; w = w - alpha d ; h = g(wtemp) + grad(wtemp).(w - wtemp) + |w - wtemp|^2 / (2 alpha)
+        while g(w) > h:  alpha *= 0.8 ; w = w - alpha d ; h = (same expression, old wtemp, new alpha) ; wtemp = w
+        w = w - alpha d                      (the reference steps once more after the loop; alpha stays shrunk)
+    Each round of the inner loop is one batched -logL + gradient call over the starts still in it."""
+    gp = _lml_gp(device)
+    W = np.array(W0, dtype=np.float64, copy=True)
+    nruns, d = W.shape
+    tol = 1e-10
+    sig = np.full(nruns, float(sigmaY))
+
+    def evaluate(P, rows):
+        nll = np.full(nruns, np.inf)
+        g = np.zeros((nruns, d))
+        st = np.ones(nruns, dtype=np.int32)
+        if len(rows):
+            a, b, c = gp.lml_batch(xTrain, yTrain, P[rows], sig[rows], kernel=kernel, grad=True)
+            nll[rows] = np.where(c == 0, a, np.inf)
+            g[rows] = np.where((c == 0)[:, None], b, 0.0)
+            st[rows] = c
+        return nll, g, st
+
+    cost, grad, stat = evaluate(W, np.arange(nruns))
+    w_hist = [[W[r].copy()] for r in range(nruns)]
+    c_hist = [[cost[r]] for r in range(nruns)]
+    exitflag = np.zeros(nruns, dtype=int)
+    active = stat == 0
+    dtemp = np.zeros_like(W)
+    alpha_r = np.full(nruns, float(alpha))
+    k = 1
+    while k <= max_its and active.any():
+        rows = np.flatnonzero(active)
+        dstep = _step_direction(norm, np.where(active[:, None], grad, 1.0), dtemp, beta, d)
+        Wt, ft, gt = W.copy(), cost.copy(), grad.copy()
+        Wn = W - alpha_r[:, None] * dstep
+        fn, gn, sn = evaluate(Wn, rows)
+        h = ft + np.sum(gt * (Wn - Wt), axis=1) + np.sum((Wn - Wt) ** 2, axis=1) / (2 * alpha_r)
+        inner = active & (sn == 0) & (fn > h)
+        failed = active & (sn != 0)
+        rounds = 0
+        while inner.any() and rounds < max_inner:
+            ir = np.flatnonzero(inner)
+            alpha_r[ir] *= 0.8
+            Wn[ir] = Wn[ir] - alpha_r[ir, None] * dstep[ir]
+            h[ir] = ft[ir] + np.sum(gt[ir] * (Wn[ir] - Wt[ir]), axis=1) + np.sum((Wn[ir] - Wt[ir]) ** 2, axis=1) / (2 * alpha_r[ir])
+            f2, g2, s2 = evaluate(Wn, ir)
+            Wt[ir], ft[ir], gt[ir] = Wn[ir], f2[ir], g2[ir]
+            fn[ir] = f2[ir]
+            failed |= inner & (s2 != 0)
+            inner = inner & (s2 == 0) & (fn > h)
+            rounds += 1
+        Wn = Wn - alpha_r[:, None] * dstep
+        good = active & ~failed
+        f3, g3, s3 = evaluate(Wn, np.flatnonzero(good))
+        failed |= good & (s3 != 0)
+        for r in rows:
+            if failed[r]:                          # left the positive-definite region: freeze at the last good point
+                active[r] = False
+                c_hist[r].append(np.inf)
+                w_hist[r].append(Wn[r].copy())
+                continue
+            moved = np.linalg.norm(Wn[r] - W[r])
+            W[r], cost[r], grad[r], dtemp[r] = Wn[r], f3[r], g3[r], dstep[r]
+            w_hist[r].append(W[r].copy())
+            c_hist[r].append(cost[r])
+            if moved < tol:
                 exitflag[r] = 1
                 active[r] = False
         k += 1

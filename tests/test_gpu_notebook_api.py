@@ -115,6 +115,43 @@ def test_multistart_hyperparameter_fit_follows_the_reference_update_rule():
     assert np.array_equal(theta, w_hist[best][-1])
 
 
+@pytest.mark.parametrize('alpha0', [0.05, 0.4])
+def test_backtracking_step_rule_follows_the_reference_loop(alpha0):
+    """steprule='backtrack' (BayesOpt_v4.ipynb:62-71), restated here start by start on the oracle's -logL and gradient,
+    against the batched device optimiser."""
+    from bayesian_optimization_amd import notebook_api as nb
+    g = golden('g1_mat_mixture')
+    xT, yT = g['xTrain'], g['yTrain']
+    nruns, max_its, beta, sY = 4, 6, 1, 0.05
+    shrunk = 0
+    x0 = 0.08 + 0.5 * o.splitmix64_uniform(33, nruns * 2).reshape(nruns, 2)
+    w_hist, c_hist, flags = nb.hypopt(nruns, max_its, alpha0, beta, 'full', 'backtrack', xT, yT, None, sY, x0=x0)
+    gfun = lambda w: o.mlefcn(xT, yT, w, sY)
+    grad = lambda w: o.mle_grad(xT, yT, w, sY)
+    for r in range(nruns):
+        w0, alpha, dtemp = x0[r].copy(), alpha0, 0.0
+        for k in range(max_its):
+            ge = grad(w0)
+            ge = ge / np.linalg.norm(ge)
+            dd = (1 - beta) * dtemp + beta * ge
+            wtemp = w0
+            w0 = w0 - alpha * dd
+            h = gfun(wtemp) + grad(wtemp) @ (w0 - wtemp) + 1 / (2 * alpha) * np.linalg.norm(w0 - wtemp) ** 2
+            while gfun(w0) > h:
+                shrunk += 1
+                alpha = 0.8 * alpha
+                w0 = w0 - alpha * dd
+                h = gfun(wtemp) + grad(wtemp) @ (w0 - wtemp) + 1 / (2 * alpha) * np.linalg.norm(w0 - wtemp) ** 2
+                wtemp = w0
+            w0 = w0 - alpha * dd
+            dtemp = dd
+        assert len(w_hist[r]) == max_its + 1
+        assert np.max(np.abs(w_hist[r][-1] - w0)) <= 1e-9, (r, w_hist[r][-1], w0)
+        assert abs(c_hist[r][-1] - gfun(w0)) <= 1e-8 * max(1.0, abs(c_hist[r][-1]))
+    if alpha0 > 0.1:
+        assert shrunk > 0          # the large first step really exercises the inner loop
+
+
 def test_continuous_acquisition_maximisation_improves_on_the_grid(gp0):
     """Grid sweep -> top-k seeds -> batched compass search (the fminsearch step of GP/BayesOpt_v2b.m:41-46):
     the refined UCB / EI is at least the grid maximum and agrees with the oracle evaluated at the refined point."""
