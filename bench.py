@@ -26,9 +26,14 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk (v_mfma_f64_16x16
 def cpu_baseline(cfg, X, y, theta, Xs_sample):
     """The oracle restatement (NumPy + LAPACK threads) timed on the host cores, on a bounded sample."""
     from oracle import gp_oracle as o
+    blas = 'unknown BLAS'
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+        info = threadpool_info()
+        cores = max([p.get('num_threads', 1) for p in info] + [1])
+        libs = sorted({'%s %s' % (p.get('internal_api', '?'), p.get('version', '')) for p in info if p.get('user_api') == 'blas'})
+        if libs:
+            blas = ', '.join(libs)
     except Exception:
         cores = os.cpu_count() or 1
     t0 = time.perf_counter()
@@ -40,8 +45,8 @@ def cpu_baseline(cfg, X, y, theta, Xs_sample):
     int(np.argmax(ei))
     t_pred = time.perf_counter() - t0
     return dict(value=len(Xs_sample) / t_pred, unit='candidates/s', cores=int(cores), kind='port',
-                sample='oracle/gp_oracle.py (NumPy/SciPy, LAPACK threads): predict+EI+argmax over the first %d candidates of '
-                       'the same workload after an untimed-in-value fit of n=%d (fit %.2f s)' % (len(Xs_sample), cfg['n'], t_fit),
+                sample='oracle/gp_oracle.py (NumPy/SciPy on %s, %d threads): predict+EI+argmax over the first %d candidates of '
+                       'the same workload after an untimed-in-value fit of n=%d (fit %.2f s)' % (blas, cores, len(Xs_sample), cfg['n'], t_fit),
                 fit_seconds=t_fit), st, (mu, var)
 
 
