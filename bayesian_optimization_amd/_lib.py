@@ -11,7 +11,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgpbo.so')
+LIB_PATH = os.environ.get('GPBO_LIBRARY') or os.path.join(_HERE, 'libgpbo.so')      # GPBO_LIBRARY: another build, for A/B timing
 
 OK, ERR_NOT_PD, ERR_BAD_ARG, ERR_HIP = 0, 1, 2, 3
 KERNEL_RBF, KERNEL_MATERN52 = 0, 1
