@@ -83,11 +83,58 @@ __device__ __forceinline__ constexpr int frag_tstride() { return KCONTIG ? 16 * 
 template <bool KCONTIG>
 __device__ __forceinline__ constexpr int frag_kstride() { return KCONTIG ? 4 : 4 * LDS_LD; }
 
+// One k-step: global loads of the next tile (one behind each of the first eight MFMAs), 64 MFMAs out of the current
+// LDS buffer, LDS stores of the next tile in the middle.  TRI: A(i, k) = 0 for k > tri_k0 + i (the diagonal block of a
+// lower-triangular operand); a 16-row block of A whose last row lies left of a 4-wide k-substep contributes nothing and
+// its four MFMAs are skipped (uniform over the wave).
+template <bool A_KCONTIG, bool B_KCONTIG, bool TRI, bool PRIO>
+__device__ __forceinline__ void gemm_k_step(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                            int kn, int k_rel, int row0, Stage& sa, Stage& sb, const double* a_l,
+                                            const double* b_l, double* nxt, f64x4 (&acc)[4][4], int tid) {
+    load_tile<A_KCONTIG>(sa, A, lda, kn, tid);
+    load_tile<B_KCONTIG>(sb, B, ldb, kn, tid);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        double af[4], bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            af[t] = a_l[kk * frag_kstride<A_KCONTIG>() + t * frag_tstride<A_KCONTIG>()];
+            bf[t] = b_l[kk * frag_kstride<B_KCONTIG>() + t * frag_tstride<B_KCONTIG>()];
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);   // a wave in its MFMA burst goes ahead of waves issuing loads and stores
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta) {
+            if (TRI && k_rel + kk * 4 > row0 + ta * 16 + 15) continue;
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (kk == 0 && !TRI) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        if (kk == 2) {   // the global data has had three k-substeps to arrive
+            store_tile<A_KCONTIG>(sa, nxt, tid);
+            store_tile<B_KCONTIG>(sb, nxt + TILE_DOUBLES, tid);
+        }
+    }
+}
+
 // acc must be zero-initialised (or hold the value to accumulate onto) by the caller.
-template <bool A_KCONTIG, bool B_KCONTIG>
+// The loads and LDS stores of the next tile are unconditional (the last step re-reads its own tile into the buffer
+// nobody reads any more), so a k-step is one basic block.  (Refilling the register stage right after its LDS store, a
+// whole k-step ahead, measured 10 % slower.)
+// tri_k0 (multiple of 16; default: none): from this k on A is the diagonal block of a lower-triangular matrix.
+// PRIO raises the wave priority over each MFMA burst: +2 % on long-k tiles (candidate sweep, trailing update), a loss
+// on the short tiles of the triangular inverse, which turn it off.
+template <bool A_KCONTIG, bool B_KCONTIG, bool PRIO = true>
 __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb,
-                                              int k_begin, int k_end, f64x4 (&acc)[4][4], double* lds) {
+                                              int k_begin, int k_end, f64x4 (&acc)[4][4], double* lds,
+                                              int tri_k0 = 0x7fffffff) {
     if (k_begin >= k_end) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -101,42 +148,19 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
     int buf = 0;
     const int a_off = frag_base<A_KCONTIG>(lane, wr * 64);
     const int b_off = TILE_DOUBLES + frag_base<B_KCONTIG>(lane, wc * 64);
-    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
-        // The loads and LDS stores of the next tile are unconditional (the last step re-reads its own tile into the
-        // buffer nobody reads any more), so the whole step is one basic block and the global loads can be placed one
-        // behind each of the first eight MFMAs instead of eight in a row in front of them.  (Refilling the register
-        // stage right after its LDS store, a whole k-step ahead, measured 10 % slower.)
+    const int k_split = tri_k0 < k_end ? (tri_k0 > k_begin ? tri_k0 : k_begin) : k_end;
+    int k0 = k_begin;
+    for (; k0 < k_split; k0 += TK) {
         const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
-        load_tile<A_KCONTIG>(sa, A, lda, kn, tid);
-        load_tile<B_KCONTIG>(sb, B, ldb, kn, tid);
-        const double* a_l = lds + buf * 2 * TILE_DOUBLES + a_off;
-        const double* b_l = lds + buf * 2 * TILE_DOUBLES + b_off;
-        double* nxt = lds + (buf ^ 1) * 2 * TILE_DOUBLES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = a_l[kk * frag_kstride<A_KCONTIG>() + t * frag_tstride<A_KCONTIG>()];
-                bf[t] = b_l[kk * frag_kstride<B_KCONTIG>() + t * frag_tstride<B_KCONTIG>()];
-            }
-#pragma unroll
-            for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-                for (int tb = 0; tb < 4; ++tb)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
-            if (kk == 0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-            }
-            if (kk == 2) {   // the global data has had three k-substeps to arrive
-                store_tile<A_KCONTIG>(sa, nxt, tid);
-                store_tile<B_KCONTIG>(sb, nxt + TILE_DOUBLES, tid);
-            }
-        }
+        gemm_k_step<A_KCONTIG, B_KCONTIG, false, PRIO>(A, lda, B, ldb, kn, 0, 0, sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off,
+                                                 lds + buf * 2 * TILE_DOUBLES + b_off, lds + (buf ^ 1) * 2 * TILE_DOUBLES, acc, tid);
+        __syncthreads();
+        buf ^= 1;
+    }
+    for (; k0 < k_end; k0 += TK) {
+        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
+        gemm_k_step<A_KCONTIG, B_KCONTIG, true, PRIO>(A, lda, B, ldb, kn, k0 - tri_k0, wr * 64, sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off,
+                                                lds + buf * 2 * TILE_DOUBLES + b_off, lds + (buf ^ 1) * 2 * TILE_DOUBLES, acc, tid);
         __syncthreads();
         buf ^= 1;
     }

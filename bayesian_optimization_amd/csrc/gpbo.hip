@@ -476,6 +476,7 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     timing_begin(ctx);
     const int nkc = (int)((ctx->n_pad + ctx->kc - 1) / ctx->kc);
     const int nb = (int)ctx->nb;
+    const bool prio = nb <= 96;   // raised MFMA-burst priority pays for short row panels only
     double trmm_launches = 0;
     {
         Scope tot(ctx, T_TOTAL);
@@ -489,11 +490,13 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                 Scope s(ctx, T_TRMM);
                 const int nj = (int)(cols / TN);
                 if (keep_v)
-                    hipLaunchKernelGGL(k_trmm_sumsq<true>, dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
+                    hipLaunchKernelGGL((prio ? k_trmm_sumsq<true, true> : k_trmm_sumsq<true, false>), dim3((unsigned)(nb * nj)),
+                                       dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n);
                 else
-                    hipLaunchKernelGGL(k_trmm_sumsq<false>, dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
+                    hipLaunchKernelGGL((prio ? k_trmm_sumsq<false, true> : k_trmm_sumsq<false, false>), dim3((unsigned)(nb * nj)),
+                                       dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0);
                 trmm_launches += 1;

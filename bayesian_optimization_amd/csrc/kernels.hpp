@@ -571,7 +571,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __r
     acc_zero(acc);
     const double* Ap = L + (long)(b0 + ib) * PB * ld + (long)a0 * PB;
     const double* Bp = W + (long)a0 * PB * ld + (long)(a0 + jb) * PB;
-    gemm_tile_128<true, false>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, lds);
+    gemm_tile_128<true, false, false>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, lds);
     double* C = T + (long)(b0 + ib) * PB * ld + (long)(a0 + jb) * PB;
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
     acc_zero(acc);
     const double* Ap = W + (long)(b0 + ib) * PB * ld + (long)b0 * PB;
     const double* Bp = T + (long)b0 * PB * ld + (long)(a0 + jb) * PB;
-    gemm_tile_128<true, false>(Ap, ld, Bp, ld, 0, (ib + 1) * PB, acc, lds);
+    gemm_tile_128<true, false, false>(Ap, ld, Bp, ld, 0, (ib + 1) * PB, acc, lds);
     double* C = W + (long)(b0 + ib) * PB * ld + (long)(a0 + jb) * PB;
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
@@ -804,7 +804,8 @@ __global__ __launch_bounds__(256) void k_ks_build(const double* __restrict__ Xs,
 // each other, so the ~512 resident tiles share one W row panel (served from L2) and the tail of a
 // launch consists of the one-k-block tiles.  An XCD-aware 8x8 super-tile order that also shares the
 // Ks panels measured 9 % slower (tiles marching through k in lockstep expose the miss latency).
-template <bool STORE_V>
+// PRIO: raised wave priority over the MFMA bursts; gains up to 2 % at 32 row blocks, loses 1.5 % at 256.
+template <bool STORE_V, bool PRIO>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __restrict__ W, long ld,
                                                              const double* __restrict__ Bmat, long ldb,
                                                              double* __restrict__ partial, int nb, int nj,
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __
     __shared__ double lds[GEMM_LDS_DOUBLES];
     f64x4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128<true, false>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds);
+    gemm_tile_128<true, false, PRIO>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds, ib * PB);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     if (STORE_V) {
