@@ -762,6 +762,7 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = round_up(n + (variant == GPBO_VARIANT_SINGLE ? ctx->reserve : 0), PB);
     CHK(ensure_model(ctx, n_pad, d, true));
+    if (d != ctx->d) ctx->m = 0;   // resident candidates have the old column count: dropped
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->inc_valid = false;
@@ -961,6 +962,7 @@ int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int32_t d, int32_t kernel, int32_
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = round_up(n, PB);
     if (n_pad != ctx->cap_pad) CHK(ensure_model(ctx, n_pad, d, false));
+    if (d != ctx->d) ctx->m = 0;
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->have_factor = false;
@@ -1011,6 +1013,7 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = round_up(n, PB);
     CHK(ensure_model(ctx, n_pad, d, true));
+    if (d != ctx->d) ctx->m = 0;
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->inc_valid = false;

@@ -84,9 +84,10 @@ class GP:
         t1, nll = C.c_double(), C.c_double()
         self._check(self._lib.gpbo_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th),
                                        float(sigmaY), int(kernel), int(variant), C.byref(t1), C.byref(nll)))
+        if X.shape[1] != self.d:
+            self.m = 0           # candidates stay resident across refits unless the column count changes
         self.n, self.d = X.shape
         self.theta1, self.nll = t1.value, nll.value
-        self.m = 0
         return self
 
     def set_candidates(self, xTest):

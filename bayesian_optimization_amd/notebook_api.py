@@ -19,6 +19,7 @@ import numpy as np
 from . import _lib as L
 from .gp import GP
 from .hyperopt import hypopt, hypopt_wrap  # noqa: F401  (BayesOpt_v4.ipynb:167-186, batched over the starts)
+from .loop import bayes_opt  # noqa: F401  (the while loop of BayesOpt_v4.ipynb:618-664)
 
 _ctx = {}
 

@@ -178,3 +178,47 @@ def test_continuous_acquisition_maximisation_improves_on_the_grid(gp0):
         assert abs(float(np.squeeze(ref)) - v) <= 1e-8 * max(abs(v), 1e-12)
         gp0.set_candidates(grid)          # restore the grid as the resident set for the next acquisition
         gp0.posterior()
+
+
+def test_outer_loop_refits_sweeps_and_appends_like_the_1d_notebook_cell():
+    """BayesOpt_v4.ipynb:618-664 end to end: per iteration the multi-start length-scale fit, the candidate sweep, EI, the
+    first-occurrence argmax and the append.  Each iteration's pick is checked against the oracle evaluated at the theta the
+    loop fitted on the training set it had at that point; the fitted theta itself against the same rule walked on the oracle."""
+    from bayesian_optimization_amd.loop import bayes_opt
+    P = 400
+    x = np.sort(-5 + 10 * o.splitmix64_uniform(12, P))[:, np.newaxis]
+    y = np.exp(-x ** 2) + np.sin(2 * x) * np.cos(10 * x)
+    ii = [37, 180, 333]
+    nruns, max_its, alpha = 4, 25, 0.01
+    starts = lambda k, d: 0.2 + 0.6 * o.splitmix64_uniform(100 + k, nruns * d).reshape(nruns, d)
+    seen = []
+
+    def check(k, s):
+        xT, yT, theta = s['xT'], s['yT'], s['theta']
+        finals, costs = [], []
+        for w in starts(k, 1):
+            w = w.copy()
+            for _ in range(max_its):
+                w = w - alpha * np.sign(o.mle_grad(xT, yT, w, 1e-2))
+            finals.append(w)
+            costs.append(o.mlefcn(xT, yT, w, 1e-2))
+        assert np.max(np.abs(theta - finals[int(np.argmin(costs))])) <= 1e-12
+        mu_o, var_o, _ = o.gprfcn_diag(x, xT, yT, theta, 1e-2)
+        ei_o = o.expected_improvement(mu_o, var_o, 0.01)
+        assert s['jj'] == int(np.argmax(ei_o))
+        assert abs(s['ei_max'] - ei_o.max()) <= 1e-8 * max(abs(ei_o.max()), 1e-3)
+        seen.append(xT.shape[0])
+
+    out = bayes_opt(x, y, x[ii], y[ii], sigmaY=1e-2, kappa=0.01, ei_tol=1e-9, nruns=nruns, max_its=max_its, alpha=alpha, beta=1,
+                    normrule='component', steprule='normal', max_iter=5, starts=starts, callback=check, keep_history=True)
+    assert seen == [3, 4, 5, 6, 7] and out['exitflag'] == 0
+    assert out['xT'].shape == (8, 1) and out['yT'].shape == (8, 1)
+    assert np.array_equal(out['xT'][3:, 0], x[out['jj_hist'], 0]) and np.array_equal(out['yT'][3:, 0], y[out['jj_hist'], 0])
+    assert len(out['Mu_hist']) == 5 and out['EI_hist'][2].shape == (P,)
+    assert int(np.argmax(out['EI_hist'][4])) == out['jj_hist'][4]
+    # stops as soon as max EI drops under the tolerance (:663-664); a callable objective is evaluated at the picked row only
+    calls = []
+    f = lambda row: (calls.append(row.copy()), np.exp(-row[0] ** 2) + np.sin(2 * row[0]) * np.cos(10 * row[0]))[1]
+    out2 = bayes_opt(x, f, x[ii], y[ii], sigmaY=1e-2, ei_tol=10.0, nruns=nruns, max_its=5, starts=starts)
+    assert out2['exitflag'] == 1 and len(out2['jj_hist']) == 1 and len(calls) == 1 and out2['xT'].shape == (4, 1)
+    assert out2['yT'][3, 0] == y[out2['jj_hist'][0], 0]
