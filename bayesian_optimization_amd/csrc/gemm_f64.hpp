@@ -124,64 +124,46 @@ __device__ __forceinline__ void gemm_k_step(const double* __restrict__ A, long l
 }
 
 // acc must be zero-initialised (or hold the value to accumulate onto) by the caller.
-// The loads and LDS stores of the next tile are unconditional, so a k-step is one basic block.  (Refilling the register
-// stage right after its LDS store, a whole k-step ahead, measured 10 % slower.)
+// The loads and LDS stores of the next tile are unconditional (the last step re-reads its own tile into the buffer
+// nobody reads any more), so a k-step is one basic block.  (Refilling the register stage right after its LDS store, a
+// whole k-step ahead, measured 10 % slower.)
 // tri_k0 (multiple of 16; default: none): from this k on A is the diagonal block of a lower-triangular matrix.
 // PRIO raises the wave priority over each MFMA burst: +2 % on long-k tiles (candidate sweep, trailing update), a loss
 // on the short tiles of the triangular inverse, which turn it off.
-//
-// Chaining (a workgroup that computes several tiles in a row): the last k-step loads k-step kbn of the operands
-// (An, Bn) -- the first k-step of the workgroup's next tile -- into the LDS buffer nobody reads any more, and returns that
-// buffer's index; the next call passes primed = true with it and starts without a prologue.  A caller with no next tile
-// passes its own operands (the step re-reads its own first tile, unused).
-template <bool A_KCONTIG, bool B_KCONTIG, bool PRIO = true>
-__device__ __forceinline__ int gemm_tile_128_chain(const double* __restrict__ A, long lda,
-                                                   const double* __restrict__ B, long ldb,
-                                                   int k_begin, int k_end, f64x4 (&acc)[4][4], double* lds, int tri_k0,
-                                                   bool primed, int buf, const double* __restrict__ An,
-                                                   const double* __restrict__ Bn, int kbn) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    Stage sa, sb;
-    if (!primed) {
-        buf = 0;
-        load_tile<A_KCONTIG>(sa, A, lda, k_begin, tid);
-        load_tile<B_KCONTIG>(sb, B, ldb, k_begin, tid);
-        store_tile<A_KCONTIG>(sa, lds, tid);
-        store_tile<B_KCONTIG>(sb, lds + TILE_DOUBLES, tid);
-        __syncthreads();
-    }
-    const int a_off = frag_base<A_KCONTIG>(lane, wr * 64);
-    const int b_off = TILE_DOUBLES + frag_base<B_KCONTIG>(lane, wc * 64);
-    const int k_split = tri_k0 < k_end ? (tri_k0 > k_begin ? tri_k0 : k_begin) : k_end;
-    int k0 = k_begin;
-    for (; k0 < k_split; k0 += TK) {
-        const bool last = (k0 + TK) >= k_end;
-        gemm_k_step<A_KCONTIG, B_KCONTIG, false, PRIO>(last ? An : A, lda, last ? Bn : B, ldb, last ? kbn : k0 + TK, 0, 0, sa, sb,
-                                                       lds + buf * 2 * TILE_DOUBLES + a_off, lds + buf * 2 * TILE_DOUBLES + b_off,
-                                                       lds + (buf ^ 1) * 2 * TILE_DOUBLES, acc, tid);
-        __syncthreads();
-        buf ^= 1;
-    }
-    for (; k0 < k_end; k0 += TK) {
-        const bool last = (k0 + TK) >= k_end;
-        gemm_k_step<A_KCONTIG, B_KCONTIG, true, PRIO>(last ? An : A, lda, last ? Bn : B, ldb, last ? kbn : k0 + TK, k0 - tri_k0, wr * 64,
-                                                      sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off, lds + buf * 2 * TILE_DOUBLES + b_off,
-                                                      lds + (buf ^ 1) * 2 * TILE_DOUBLES, acc, tid);
-        __syncthreads();
-        buf ^= 1;
-    }
-    return buf;
-}
-
 template <bool A_KCONTIG, bool B_KCONTIG, bool PRIO = true>
 __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb,
                                               int k_begin, int k_end, f64x4 (&acc)[4][4], double* lds,
                                               int tri_k0 = 0x7fffffff) {
     if (k_begin >= k_end) return;
-    gemm_tile_128_chain<A_KCONTIG, B_KCONTIG, PRIO>(A, lda, B, ldb, k_begin, k_end, acc, lds, tri_k0, false, 0, A, B, k_begin);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    Stage sa, sb;
+    load_tile<A_KCONTIG>(sa, A, lda, k_begin, tid);
+    load_tile<B_KCONTIG>(sb, B, ldb, k_begin, tid);
+    store_tile<A_KCONTIG>(sa, lds, tid);
+    store_tile<B_KCONTIG>(sb, lds + TILE_DOUBLES, tid);
+    __syncthreads();
+    int buf = 0;
+    const int a_off = frag_base<A_KCONTIG>(lane, wr * 64);
+    const int b_off = TILE_DOUBLES + frag_base<B_KCONTIG>(lane, wc * 64);
+    const int k_split = tri_k0 < k_end ? (tri_k0 > k_begin ? tri_k0 : k_begin) : k_end;
+    int k0 = k_begin;
+    for (; k0 < k_split; k0 += TK) {
+        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
+        gemm_k_step<A_KCONTIG, B_KCONTIG, false, PRIO>(A, lda, B, ldb, kn, 0, 0, sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off,
+                                                 lds + buf * 2 * TILE_DOUBLES + b_off, lds + (buf ^ 1) * 2 * TILE_DOUBLES, acc, tid);
+        __syncthreads();
+        buf ^= 1;
+    }
+    for (; k0 < k_end; k0 += TK) {
+        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
+        gemm_k_step<A_KCONTIG, B_KCONTIG, true, PRIO>(A, lda, B, ldb, kn, k0 - tri_k0, wr * 64, sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off,
+                                                lds + buf * 2 * TILE_DOUBLES + b_off, lds + (buf ^ 1) * 2 * TILE_DOUBLES, acc, tid);
+        __syncthreads();
+        buf ^= 1;
+    }
 }
 
 // Accumulator element acc[ta][tb][r] of this lane is output (row, col) of the tile:

@@ -31,7 +31,6 @@ struct EvRec {
 
 struct gpbo_ctx {
     int device = 0;
-    int num_cus = 256;                      // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     hipStream_t stream = nullptr;
     hipStream_t pstream = nullptr;          // high-priority stream of the Cholesky panel work (created on first use)
     hipStream_t bstream = nullptr;          // bulk trailing updates beside it; CU-masked so a CU per XCD stays free for the diagonal blocks
@@ -95,8 +94,6 @@ struct gpbo_ctx {
     // chunk scratch
     int64_t chunk_req = 0, chunk = 0, scratch_npad = 0;
     double *Bmat = nullptr, *partial = nullptr, *mupart = nullptr;
-    int* tile_ctr = nullptr;                // one tile counter per candidate-sweep launch of a posterior call
-    int64_t tile_ctr_cap = 0;
     int kc = 512;
 
     // reductions
@@ -476,12 +473,6 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
         }
     }
     ctx->inc_valid = false;
-    const int64_t n_launch = (ctx->m + ctx->chunk - 1) / ctx->chunk;
-    if (n_launch > ctx->tile_ctr_cap) {
-        CHK(dev_alloc(ctx, &ctx->tile_ctr, (size_t)n_launch));
-        ctx->tile_ctr_cap = n_launch;
-    }
-    HIPCHK(hipMemsetAsync(ctx->tile_ctr, 0, (size_t)n_launch * sizeof(int), ctx->stream));
     timing_begin(ctx);
     const int nkc = (int)((ctx->n_pad + ctx->kc - 1) / ctx->kc);
     const int nb = (int)ctx->nb;
@@ -498,21 +489,18 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
             {
                 Scope s(ctx, T_TRMM);
                 const int nj = (int)(cols / TN);
-                const int64_t launch_no = j0 / ctx->chunk;
                 int cg = std::min(nj, 128);   // column blocks per tile-order group
                 if (const char* e = getenv("GPBO_TRMM_COLGROUP")) cg = std::max(1, std::min(nj, atoi(e)));
-                int pgrid = 2 * ctx->num_cus;          // two workgroups per CU stay resident and walk the tiles
-                if (const char* e = getenv("GPBO_TRMM_GRID")) pgrid = std::max(1, atoi(e));
                 if (keep_v)
-                    hipLaunchKernelGGL((prio ? k_trmm_sumsq<true, true> : k_trmm_sumsq<true, false>), dim3((unsigned)std::min(nb * nj, pgrid)),
+                    hipLaunchKernelGGL((prio ? k_trmm_sumsq<true, true> : k_trmm_sumsq<true, false>), dim3((unsigned)(nb * nj)),
                                        dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
-                                       ctx->partial, nb, nj, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n, cg, ctx->tile_ctr + launch_no);
+                                       ctx->partial, nb, nj, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n, cg);
                 else
-                    hipLaunchKernelGGL((prio ? k_trmm_sumsq<false, true> : k_trmm_sumsq<false, false>), dim3((unsigned)std::min(nb * nj, pgrid)),
+                    hipLaunchKernelGGL((prio ? k_trmm_sumsq<false, true> : k_trmm_sumsq<false, false>), dim3((unsigned)(nb * nj)),
                                        dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
-                                       ctx->partial, nb, nj, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0, cg, ctx->tile_ctr + launch_no);
+                                       ctx->partial, nb, nj, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0, cg);
                 trmm_launches += 1;
             }
             {
@@ -718,8 +706,6 @@ int gpbo_create(int device, gpbo_ctx** out) {
         return GPBO_ERR_HIP;
     }
     hipMemset(ctx->params, 0, PARAMS_DOUBLES * sizeof(double));
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus;
     *out = ctx;
     return GPBO_OK;
 }
@@ -735,7 +721,7 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     free_model(ctx);
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
                   ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
-                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres,  ctx->tile_ctr};
+                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres};
     for (void* p : ps)
         if (p) hipFree(p);
     for (auto e : ctx->pool) hipEventDestroy(e);

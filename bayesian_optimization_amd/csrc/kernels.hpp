@@ -805,81 +805,59 @@ __global__ __launch_bounds__(256) void k_ks_build(const double* __restrict__ Xs,
 // of a launch consists of one-k-block tiles.  Groups of 128 column blocks against one group of 256 (the whole chunk):
 // +2.4 % on two machines, -0.2 % on a third that ran both at the higher rate; narrower groups lose (48: -3 %, 8: -9 %);
 // alternating heavy and light row blocks loses 1-2 %.  An XCD-aware 8x8 super-tile order that also shares the Ks panels
-// measured 9 % slower (tiles marching through k in lockstep expose the miss latency).
+// measured 9 % slower (tiles marching through k in lockstep expose the miss latency).  Persistent workgroups that chain
+// their tiles (no prologue) and draw them from a counter: +0.7 % with one counter but 20 GB instead of 12 GB fetched per
+// launch (the row blocks of a column block no longer meet in one L2), -0.5 % with a counter per XCD; with a static
+// assignment -4 % (workgroups do not progress at equal rates).  The hardware dispatcher's order stays.
 // PRIO: raised wave priority over the MFMA bursts; gains up to 2 % at 32 row blocks, loses 1.5 % at 256.
 template <bool STORE_V, bool PRIO>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __restrict__ W, long ld,
                                                              const double* __restrict__ Bmat, long ldb,
                                                              double* __restrict__ partial, int nb, int nj,
                                                              double* __restrict__ Vres, long ldv, long j0, long m, int v_rows,
-                                                             int cg, int* __restrict__ counter) {
+                                                             int cg) {
+    const int per = nb * cg;
+    const int grp = blockIdx.x / per, r = blockIdx.x % per;
+    const int cw = min(cg, nj - grp * cg);              // the last group may be narrower
+    const int ib = nb - 1 - r / cw;
+    const int jb = grp * cg + r % cw;
     __shared__ double lds[GEMM_LDS_DOUBLES];
-    __shared__ double red[256];
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128<true, false, PRIO>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds, ib * PB);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
-    const int per = nb * cg, ntiles = nb * nj;
-    int buf = 0;
-    bool primed = false;
-    // A workgroup walks tiles: its first two are blockIdx.x and blockIdx.x + gridDim.x, the following ones come from a
-    // counter (first come, first served), fetched one tile ahead so that nobody waits for the atomic: the index read at the
-    // top of a tile was requested at the top of the tile before.  The first k-step of the next tile is already in LDS
-    // when the current tile's epilogue starts.
-    __shared__ int s_next[2];
-    int t = blockIdx.x;
-    int tn = t + (int)gridDim.x;
-    for (int it = 0; t < ntiles; ++it) {
-        if (tid == 0) s_next[it & 1] = 2 * (int)gridDim.x + atomicAdd(counter, 1);     // the tile after the next
-        const bool has_next = tn < ntiles;
-        // groups of cg column blocks; inside a group row blocks heaviest first, the group's column blocks adjacent
-        const int grp = t / per, r = t % per;
-        const int cw = min(cg, nj - grp * cg);              // the last group may be narrower
-        const int ib = nb - 1 - r / cw;
-        const int jb = grp * cg + r % cw;
-        const int tq = has_next ? tn : t;
-        const int grpn = tq / per, rn = tq % per;
-        const int cwn = min(cg, nj - grpn * cg);
-        const int ibn = nb - 1 - rn / cwn;
-        const int jbn = grpn * cg + rn % cwn;
-        f64x4 acc[4][4];
-        acc_zero(acc);
-        buf = gemm_tile_128_chain<true, false, PRIO>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds,
-                                                     ib * PB, primed, buf, W + (long)ibn * PB * ld, Bmat + (long)jbn * TN, 0);
-        primed = true;
-        if (STORE_V) {
+    if (STORE_V) {
 #pragma unroll
-            for (int ta = 0; ta < 4; ++ta)
+        for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-                for (int tb = 0; tb < 4; ++tb)
+            for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const int row = ib * PB + acc_row(ta, r4);
-                        const long col = j0 + (long)jb * TN + acc_col(tb);
-                        if (row < v_rows && col < m) Vres[(long)row * ldv + col] = acc[ta][tb][r4];
-                    }
-        }
-        double cs[4];
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
-            double s = 0.0;
-#pragma unroll
-            for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) s += acc[ta][tb][r4] * acc[ta][tb][r4];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            cs[tb] = s;
-        }
-        if ((lane >> 4) == 0) {
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) red[wr * 128 + wc * 64 + tb * 16 + lane] = cs[tb];
-        }
-        __syncthreads();
-        if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
-        // the next tile's k-steps end on barriers before red is written again; s_next[it & 1] was written before this
-        // tile's barriers
-        t = tn;
-        tn = s_next[it & 1];
+                for (int r = 0; r < 4; ++r) {
+                    const int row = ib * PB + acc_row(ta, r);
+                    const long col = j0 + (long)jb * TN + acc_col(tb);
+                    if (row < v_rows && col < m) Vres[(long)row * ldv + col] = acc[ta][tb][r];
+                }
     }
+    double cs[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        double s = 0.0;
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += acc[ta][tb][r] * acc[ta][tb][r];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        cs[tb] = s;
+    }
+    double* red = lds;   // the tile engine ended on a barrier: LDS is free
+    if ((lane >> 4) == 0) {
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) red[wr * 128 + wc * 64 + tb * 16 + lane] = cs[tb];
+    }
+    __syncthreads();
+    if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
 }
 
 // Trend basis of the kriging flavour (polymat, Gaussian_Process_Regression.ipynb:113-140): columns for

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Kernel-trace statistics and the three counter passes of the default bench configuration; run on the GPU box from the
+# repository root.  Summaries land in gpurun_out/prof_r1/ (copy what is to be kept into profiles/).
+set -o pipefail
+cd "$(dirname "$0")/.." || exit 1
+R=$PWD
+O=$R/gpurun_out/prof_r1
+mkdir -p "$O"
+export TMPDIR=/tmp
+cd /tmp || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o kt -- python3 "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/kt.err" || exit 1
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$O/fetch" -o f -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$O/f.err" || exit 1
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$O/write" -o w -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$O/w.err" || exit 1
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d "$O/sq" -o s -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$O/s.err" || exit 1
+cd "$R" || exit 1
+python3 scripts/summarize_pmc.py $(find "$O/fetch" "$O/write" "$O/sq" -name '*counter_collection.csv' | sort) > "$O/pmc_summary.txt"
+cp $(find "$O/kt" -name '*kernel_stats.csv' | head -1) "$O/kernel_stats.csv"
+find "$O" -name '*.db' -delete; find "$O" -name '*counter_collection.csv' -size +20M -delete
+timeout -k 10 300 python3 bench.py > "$O/bench.json" 2> "$O/bench.err" || exit 1
+head -5 "$O/kernel_stats.csv"; head -4 "$O/pmc_summary.txt"; cat "$O/bench.json"
