@@ -292,6 +292,16 @@ def main():
                                    'trmm_sumsq': trmm_ms / a.steps, 'acquire': acq_ms / a.steps},
             'argmax': {'index': int(gidx), 'ei': gbest, 'mu_max': mu_max},
         }
+        # every phase against its own bound, and the time-weighted combination over the sweep
+        ks_s, other_s = ks_ms * 1e-3, max(post_ms + acq_ms - ks_ms - trmm_ms, 0.0) * 1e-3
+        cand = float(m_per_gpu * a.steps)
+        ks_gbs = 8.0 * n * cand / max(ks_s, 1e-12) / 1e9                   # the Ks panel: 8 n bytes written per candidate
+        other_gbs = (8.0 * cfg['d'] + 48.0) * cand / max(other_s, 1e-12) / 1e9   # read x*, write mu/var/ei, EI pass re-reads mu/var
+        ph = [('trmm_sumsq', 'mfma', trmm_ms * 1e-3, achieved / FP64_MFMA_PEAK_TFLOPS),
+              ('ks_build', 'hbm', ks_s, ks_gbs / 8000.0), ('finalize+acquire+reductions', 'hbm', other_s, other_gbs / 8000.0)]
+        tsum = sum(t for _, _, t, _ in ph)
+        out['phase_rooflines'] = {'phases': [{'phase': k, 'bound': b, 'ms_per_step': t / a.steps * 1e3, 'frac': f} for k, b, t, f in ph],
+                                  'time_weighted_frac': sum(t * f for _, _, t, f in ph) / max(tsum, 1e-12)}
         if fit_tm:
             nchol = max(fit_tm['chol_count'], 1)
             out['fit'] = {'total_ms': fit_tm['fit_total_ms'], 'cholesky_ms_each': fit_tm['chol_ms'] / nchol,
