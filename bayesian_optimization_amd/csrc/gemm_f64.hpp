@@ -87,26 +87,40 @@ __device__ __forceinline__ constexpr int frag_kstride() { return KCONTIG ? 4 : 4
 // LDS buffer, LDS stores of the next tile in the middle.  TRI: A(i, k) = 0 for k > tri_k0 + i (the diagonal block of a
 // lower-triangular operand); a 16-row block of A whose last row lies left of a 4-wide k-substep contributes nothing and
 // its four MFMAs are skipped (uniform over the wave).
-template <bool A_KCONTIG, bool B_KCONTIG, bool TRI, bool PRIO>
+template <bool A_KCONTIG, bool B_KCONTIG, bool TRI, int MODE>
 __device__ __forceinline__ void gemm_k_step(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                             int kn, int k_rel, int row0, Stage& sa, Stage& sb, const double* a_l,
                                             const double* b_l, double* nxt, f64x4 (&acc)[4][4], int tid) {
     load_tile<A_KCONTIG>(sa, A, lda, kn, tid);
     load_tile<B_KCONTIG>(sb, B, ldb, kn, tid);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        double af[4], bf[4];
+    constexpr bool PRIO = MODE >= 1, PREF = MODE == 2;
+    // PREF: the fragments of k-substep kk + 1 are requested before the MFMA burst of kk (the priority switches fence the
+    // scheduler, so the reads stay in front of the burst and have a whole burst to land)
+    double af[2][4], bf[2][4];
+    if (PREF) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            af[t] = a_l[kk * frag_kstride<A_KCONTIG>() + t * frag_tstride<A_KCONTIG>()];
-            bf[t] = b_l[kk * frag_kstride<B_KCONTIG>() + t * frag_tstride<B_KCONTIG>()];
+            af[0][t] = a_l[t * frag_tstride<A_KCONTIG>()];
+            bf[0][t] = b_l[t * frag_tstride<B_KCONTIG>()];
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int kr = PREF ? kk + 1 : kk, slot = PREF ? (kk + 1) & 1 : kk & 1;
+        if (kr < 4) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[slot][t] = a_l[kr * frag_kstride<A_KCONTIG>() + t * frag_tstride<A_KCONTIG>()];
+                bf[slot][t] = b_l[kr * frag_kstride<B_KCONTIG>() + t * frag_tstride<B_KCONTIG>()];
+            }
         }
         if (PRIO) __builtin_amdgcn_s_setprio(1);   // a wave in its MFMA burst goes ahead of waves issuing loads and stores
 #pragma unroll
         for (int ta = 0; ta < 4; ++ta) {
             if (TRI && k_rel + kk * 4 > row0 + ta * 16 + 15) continue;
 #pragma unroll
-            for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
+            for (int tb = 0; tb < 4; ++tb)
+                acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][ta], bf[kk & 1][tb], acc[ta][tb], 0, 0, 0);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         if (kk == 0 && !TRI) {
@@ -128,9 +142,11 @@ __device__ __forceinline__ void gemm_k_step(const double* __restrict__ A, long l
 // nobody reads any more), so a k-step is one basic block.  (Refilling the register stage right after its LDS store, a
 // whole k-step ahead, measured 10 % slower.)
 // tri_k0 (multiple of 16; default: none): from this k on A is the diagonal block of a lower-triangular matrix.
-// PRIO raises the wave priority over each MFMA burst: +2 % on long-k tiles (candidate sweep, trailing update), a loss
-// on the short tiles of the triangular inverse, which turn it off.
-template <bool A_KCONTIG, bool B_KCONTIG, bool PRIO = true>
+// MODE 1 raises the wave priority over each MFMA burst: +2 % on the trailing update of the factorisation, a loss on the
+// short tiles of the triangular inverse (MODE 0).  MODE 2 also requests the LDS fragments one k-substep ahead: +2 % on the
+// candidate sweep with short row panels; without the priority switches (which fence the instruction scheduler) the
+// compiler sinks the reads back to their use, and on the factorisation's short products it loses 4 %.
+template <bool A_KCONTIG, bool B_KCONTIG, int MODE = 1>
 __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb,
                                               int k_begin, int k_end, f64x4 (&acc)[4][4], double* lds,
@@ -152,14 +168,14 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
     int k0 = k_begin;
     for (; k0 < k_split; k0 += TK) {
         const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
-        gemm_k_step<A_KCONTIG, B_KCONTIG, false, PRIO>(A, lda, B, ldb, kn, 0, 0, sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off,
+        gemm_k_step<A_KCONTIG, B_KCONTIG, false, MODE>(A, lda, B, ldb, kn, 0, 0, sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off,
                                                  lds + buf * 2 * TILE_DOUBLES + b_off, lds + (buf ^ 1) * 2 * TILE_DOUBLES, acc, tid);
         __syncthreads();
         buf ^= 1;
     }
     for (; k0 < k_end; k0 += TK) {
         const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
-        gemm_k_step<A_KCONTIG, B_KCONTIG, true, PRIO>(A, lda, B, ldb, kn, k0 - tri_k0, wr * 64, sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off,
+        gemm_k_step<A_KCONTIG, B_KCONTIG, true, MODE>(A, lda, B, ldb, kn, k0 - tri_k0, wr * 64, sa, sb, lds + buf * 2 * TILE_DOUBLES + a_off,
                                                 lds + buf * 2 * TILE_DOUBLES + b_off, lds + (buf ^ 1) * 2 * TILE_DOUBLES, acc, tid);
         __syncthreads();
         buf ^= 1;

@@ -476,7 +476,8 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     timing_begin(ctx);
     const int nkc = (int)((ctx->n_pad + ctx->kc - 1) / ctx->kc);
     const int nb = (int)ctx->nb;
-    const bool prio = nb <= 96;   // raised MFMA-burst priority pays for short row panels only
+    int mode = 2;   // tile engine scheduling: priority raise over the MFMA bursts + fragment prefetch
+    if (const char* e = getenv("GPBO_TRMM_MODE")) mode = atoi(e);
     double trmm_launches = 0;
     {
         Scope tot(ctx, T_TOTAL);
@@ -492,12 +493,12 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                 int cg = std::min(nj, 128);   // column blocks per tile-order group
                 if (const char* e = getenv("GPBO_TRMM_COLGROUP")) cg = std::max(1, std::min(nj, atoi(e)));
                 if (keep_v)
-                    hipLaunchKernelGGL((prio ? k_trmm_sumsq<true, true> : k_trmm_sumsq<true, false>), dim3((unsigned)(nb * nj)),
+                    hipLaunchKernelGGL((mode == 2 ? k_trmm_sumsq<true, 2> : mode == 1 ? k_trmm_sumsq<true, 1> : k_trmm_sumsq<true, 0>), dim3((unsigned)(nb * nj)),
                                        dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n, cg);
                 else
-                    hipLaunchKernelGGL((prio ? k_trmm_sumsq<false, true> : k_trmm_sumsq<false, false>), dim3((unsigned)(nb * nj)),
+                    hipLaunchKernelGGL((mode == 2 ? k_trmm_sumsq<false, 2> : mode == 1 ? k_trmm_sumsq<false, 1> : k_trmm_sumsq<false, 0>), dim3((unsigned)(nb * nj)),
                                        dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0, cg);

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __r
     acc_zero(acc);
     const double* Ap = L + (long)(b0 + ib) * PB * ld + (long)a0 * PB;
     const double* Bp = W + (long)a0 * PB * ld + (long)(a0 + jb) * PB;
-    gemm_tile_128<true, false, false>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, lds);
+    gemm_tile_128<true, false, 0>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, lds);
     double* C = T + (long)(b0 + ib) * PB * ld + (long)(a0 + jb) * PB;
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
     acc_zero(acc);
     const double* Ap = W + (long)(b0 + ib) * PB * ld + (long)b0 * PB;
     const double* Bp = T + (long)b0 * PB * ld + (long)(a0 + jb) * PB;
-    gemm_tile_128<true, false, false>(Ap, ld, Bp, ld, 0, (ib + 1) * PB, acc, lds);
+    gemm_tile_128<true, false, 0>(Ap, ld, Bp, ld, 0, (ib + 1) * PB, acc, lds);
     double* C = W + (long)(b0 + ib) * PB * ld + (long)(a0 + jb) * PB;
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
@@ -809,8 +809,9 @@ __global__ __launch_bounds__(256) void k_ks_build(const double* __restrict__ Xs,
 // their tiles (no prologue) and draw them from a counter: +0.7 % with one counter but 20 GB instead of 12 GB fetched per
 // launch (the row blocks of a column block no longer meet in one L2), -0.5 % with a counter per XCD; with a static
 // assignment -4 % (workgroups do not progress at equal rates).  The hardware dispatcher's order stays.
-// PRIO: raised wave priority over the MFMA bursts; gains up to 2 % at 32 row blocks, loses 1.5 % at 256.
-template <bool STORE_V, bool PRIO>
+// MODE: the tile engine's scheduling mode; 2 (priority raise + fragment prefetch) is never worse than 0 or 1 here: equal to
+// the better of them at 32 row blocks, whichever that is on the machine at hand, and +0.9 % at 256.
+template <bool STORE_V, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __restrict__ W, long ld,
                                                              const double* __restrict__ Bmat, long ldb,
                                                              double* __restrict__ partial, int nb, int nj,
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __
     __shared__ double lds[GEMM_LDS_DOUBLES];
     f64x4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128<true, false, PRIO>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds, ib * PB);
+    gemm_tile_128<true, false, MODE>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds, ib * PB);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     if (STORE_V) {
