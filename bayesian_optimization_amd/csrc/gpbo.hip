@@ -252,7 +252,7 @@ int ensure_scratch(gpbo_ctx* ctx) {
 // ---------------------------------------------------------------- launch sequences
 int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, double eps, const double* eps_ptr = nullptr) {
     Scope s(ctx, T_KBUILD);
-    dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4), (unsigned)ctx->batch);
+    dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 32), (unsigned)ctx->batch);
     hipLaunchKernelGGL(k_kernel_matrix, grid, dim3(256), 0, ctx->stream, ctx->Xts, (int)ctx->n, (int)ctx->n_pad, ctx->d, K,
                        scale_ptr, eps, eps_ptr, ctx->kernel, ctx->bs);
     HIPCHK(hipGetLastError());
