@@ -1059,11 +1059,16 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
         ctx->err = "kriging_fit: hipMalloc failed";
         return GPBO_ERR_HIP;
     }
-    hipMemcpyAsync(ctx->Xts, xts.data(), xts.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-    hipMemcpyAsync(ctx->params, par.data(), par.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-    hipMemcpyAsync(rhs_dev, rhs.data(), rhs.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-    hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream);
-    hipStreamSynchronize(ctx->stream);
+    hipError_t up = hipMemcpyAsync(ctx->Xts, xts.data(), xts.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (up == hipSuccess) up = hipMemcpyAsync(ctx->params, par.data(), par.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (up == hipSuccess) up = hipMemcpyAsync(rhs_dev, rhs.data(), rhs.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (up == hipSuccess) up = hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream);
+    if (up == hipSuccess) up = hipStreamSynchronize(ctx->stream);
+    if (up != hipSuccess) {
+        cleanup();
+        ctx->err = std::string("kriging_fit: upload failed: ") + hipGetErrorString(up);
+        return GPBO_ERR_HIP;
+    }
     timing_begin(ctx);
     int st = GPBO_OK;
     {
@@ -1223,9 +1228,15 @@ int gpbo_kernel_matrix(gpbo_ctx* ctx, const double* U, int64_t p, const double* 
         ctx->err = "kernel_matrix: hipMalloc failed";
         return GPBO_ERR_HIP;
     }
-    hipMemcpyAsync(du, U, (size_t)p * d * 8, hipMemcpyHostToDevice, ctx->stream);
-    hipMemcpyAsync(dv, V, (size_t)q * d * 8, hipMemcpyHostToDevice, ctx->stream);
-    hipMemcpyAsync(dth, ith.data(), (size_t)d * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t up = hipMemcpyAsync(du, U, (size_t)p * d * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (up == hipSuccess) up = hipMemcpyAsync(dv, V, (size_t)q * d * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (up == hipSuccess) up = hipMemcpyAsync(dth, ith.data(), (size_t)d * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (up != hipSuccess) {
+        hipStreamSynchronize(ctx->stream);
+        cleanup();
+        ctx->err = std::string("kernel_matrix: upload failed: ") + hipGetErrorString(up);
+        return GPBO_ERR_HIP;
+    }
     hipLaunchKernelGGL(k_cross_kernel, dim3((unsigned)((q + 63) / 64), (unsigned)((p + 3) / 4)), dim3(256), 0, ctx->stream,
                        (const double*)du, (long)p, (const double*)dv, (long)q, (int)d, (const double*)dth, kernel, dk);
     hipError_t e1 = hipMemcpyAsync(K_out, dk, (size_t)p * q * 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -1260,8 +1271,14 @@ int gpbo_kernel_from_distances(gpbo_ctx* ctx, const double* Dabs, int32_t d, int
         ctx->err = "kernel_from_distances: hipMalloc failed";
         return GPBO_ERR_HIP;
     }
-    hipMemcpyAsync(dd, Dabs, pq * d * 8, hipMemcpyHostToDevice, ctx->stream);
-    hipMemcpyAsync(dth, ith.data(), (size_t)d * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t up = hipMemcpyAsync(dd, Dabs, pq * d * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (up == hipSuccess) up = hipMemcpyAsync(dth, ith.data(), (size_t)d * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (up != hipSuccess) {
+        hipStreamSynchronize(ctx->stream);
+        cleanup();
+        ctx->err = std::string("kernel_from_distances: upload failed: ") + hipGetErrorString(up);
+        return GPBO_ERR_HIP;
+    }
     hipLaunchKernelGGL(k_kernel_from_absdiff, dim3((unsigned)((pq + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)dd,
                        (long)pq, (int)d, (const double*)dth, kernel, dk);
     hipError_t e1 = hipMemcpyAsync(K_out, dk, pq * 8, hipMemcpyDeviceToHost, ctx->stream);
