@@ -43,7 +43,7 @@ constexpr int R_NB = 4;
 template <int ABL>
 __global__ __launch_bounds__(256, 2) void k_ring(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                                  double* __restrict__ C, int n) {
-    __shared__ __attribute__((aligned(16))) double lds[R_NB * R_STAGE];
+    __shared__ __attribute__((aligned(16))) double lds[R_NB * R_STAGE + 128];     // + the prefetch dump area
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
     const double* Ap = A + (long)blockIdx.y * 128 * lda;
     const double* Bp = B + (long)blockIdx.x * 128;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void k_ring(const double* __restrict__ A, l
     const double* gb1 = gb0 + ldb;
     auto issue = [&](int step) {
         double* st = lds + (step & (R_NB - 1)) * R_STAGE;
-        const long ko = (long)step * RK;
+        const long ko = ((ABL & 255) & 8) ? 0 : (long)step * RK;     // bit 3: every step re-reads k-step 0 (hot in L2)
         __builtin_amdgcn_global_load_lds((glob_void_t*)(ga0 + ko), (lds_void_t*)(st + (w * 32) * RK), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glob_void_t*)(ga1 + ko), (lds_void_t*)(st + (w * 32 + 16) * RK), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glob_void_t*)(gb0 + ko * ldb), (lds_void_t*)(st + R_A + (2 * w) * RB_LD), 16, 0, 0);
@@ -81,6 +81,16 @@ __global__ __launch_bounds__(256, 2) void k_ring(const double* __restrict__ A, l
             bf[t] = st[boff + kk * 4 * RB_LD + t * 16];
         }
     };
+    constexpr int PF = ABL >> 8;      // software L2 prefetch distance in k-steps (0: off)
+    // one touch per wave and k-step: waves 0/1 a 4-byte read from each of the 128 A rows' 64-byte segments, waves 2/3 from
+    // the 64 128-byte lines of the 8 B rows
+    const double* pf_ptr = (w < 2) ? Ap + (long)(w * 64 + lane) * lda : Bp + (long)(lane >> 3) * ldb + 16 * (lane & 7);
+    const long pf_step = (w < 2) ? (long)RK : (long)RK * ldb;
+    // the touch is an LDS-DMA load of 4 bytes per lane into a per-wave dump area: no register is written behind the compiler's back
+    auto prefetch = [&](int step) {
+        const double* q = pf_ptr + (long)step * pf_step;
+        __builtin_amdgcn_global_load_lds((glob_void_t*)q, (lds_void_t*)(lds + R_NB * R_STAGE + w * 32), 4, 0, 0);
+    };
     const int nsteps = n / RK;
     issue(0);
     issue(1);
@@ -93,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void k_ring(const double* __restrict__ A, l
         const double* cur = lds + (s & (R_NB - 1)) * R_STAGE;
         const double* nx = lds + ((s + 1) & (R_NB - 1)) * R_STAGE;
         const bool more = s + 3 < nsteps;
+        if (PF > 0 && s + PF < nsteps) prefetch(s + PF);     // issued before this step's loads: one more op may stay in flight
         if (more && !(ABL & 1)) issue(s + 3);
         // both fragment sets needed next are requested here, a whole burst before their first use: substep 1 of this
         // k-step and substep 0 of the next one (complete in LDS since the previous barrier; garbage past the last step)
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_ring(const double* __restrict__ A, l
             a0[t] = an[t];
             b0[t] = bn[t];
         }
-        if (more && !(ABL & 1)) WAIT_VM(4);   // tile s + 2 has landed; tile s + 3 may still be in flight
+        if (more && !(ABL & 1)) { if (PF > 0 && s + PF < nsteps) WAIT_VM(5); else WAIT_VM(4); }   // tile s + 2 has landed; tile s + 3 may still be in flight
         else WAIT_VM(0);
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
     }
@@ -181,6 +192,11 @@ int main() {
         run("ring, no loads (timing only)", [&] { k_ring<1><<<grid, 256>>>(A, n, B, n, C, n); }, C, n, ref);
         run("ring, no barrier (timing only)", [&] { k_ring<2><<<grid, 256>>>(A, n, B, n, C, n); }, C, n, ref);
         run("ring, neither (timing only)", [&] { k_ring<3><<<grid, 256>>>(A, n, B, n, C, n); }, C, n, ref);
+        run("ring + L2 prefetch 8 steps", [&] { k_ring<(8 << 8)><<<grid, 256>>>(A, n, B, n, C, n); }, C, n, ref);
+        run("ring + L2 prefetch 16 steps", [&] { k_ring<(16 << 8)><<<grid, 256>>>(A, n, B, n, C, n); }, C, n, ref);
+        run("ring + L2 prefetch 32 steps", [&] { k_ring<(32 << 8)><<<grid, 256>>>(A, n, B, n, C, n); }, C, n, ref);
+        run("ring, loads of k-step 0 only", [&] { k_ring<8><<<grid, 256>>>(A, n, B, n, C, n); }, C, n, ref);
+        run("ring, k-step 0 loads, no barrier", [&] { k_ring<10><<<grid, 256>>>(A, n, B, n, C, n); }, C, n, ref);
     }
     return 0;
 }
