@@ -54,6 +54,7 @@ SIGNATURES = {
     'gpbo_stream': (C.c_void_p, [C.c_void_p]),
     'gpbo_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, C.c_double, C.c_int32, C.c_int32, _dp, _dp]),
     'gpbo_set_candidates': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    'gpbo_set_candidates_uniform': (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64]),
     'gpbo_posterior': (C.c_int, [C.c_void_p, _dp]),
     'gpbo_acquire': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, _i64p, _dp]),
     'gpbo_read': (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int64, C.c_int64]),
@@ -70,7 +71,7 @@ SIGNATURES = {
     'gpbo_cond_estimate': (C.c_int, [C.c_void_p, _dp]),
     'gpbo_last_timings': (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     'gpbo_state_describe': (C.c_int, [C.c_void_p, C.POINTER(StateDesc)]),
-    'gpbo_state_alloc': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
+    'gpbo_state_alloc': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     'gpbo_state_commit': (C.c_int, [C.c_void_p, C.c_double]),
     'gpbo_set_chunk': (C.c_int, [C.c_void_p, C.c_int64]),
     'gpbo_selftest_gemm': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -77,6 +79,7 @@ struct gpbo_ctx {
     hipGraphExec_t lane_graph = nullptr;
     std::vector<int64_t> lane_graph_key;
     size_t params_cap = PARAMS_DOUBLES, slot_cap = 0;
+    int64_t alloc_gen = 0;      // bumped whenever a buffer a captured launch sequence names is (re)allocated
     bool no_timing = false;     // set while a launch sequence is captured into a graph
     int batch = 1;              // > 1: a batched context, every model buffer holds `batch` slots (see BatchStride)
     BatchStride bs;
@@ -88,6 +91,7 @@ struct gpbo_ctx {
     // candidates + outputs
     double* Xs = nullptr;
     int64_t m = 0, m_cap = 0, xs_cap = 0;   // m_cap: outputs (doubles per array); xs_cap: doubles in Xs
+    int64_t xs_rows = 0;                    // candidate rows resident in Xs (m may differ after gpbo_set_posterior)
     double *mu = nullptr, *var = nullptr, *acq = nullptr;
     bool have_posterior = false;
 
@@ -195,6 +199,12 @@ void free_model(gpbo_ctx* ctx) {
     ctx->cap_pad = 0;
     ctx->fitted = false;
     ctx->have_factor = false;
+    ctx->alloc_gen += 1;
+    if (ctx->lane_graph) {       // its launches name the buffers just freed
+        hipGraphExecDestroy(ctx->lane_graph);
+        ctx->lane_graph = nullptr;
+    }
+    ctx->lane_graph_key.clear();
 }
 
 // (re)allocate model buffers for n_pad; full = also the factor buffers (fit ranks)
@@ -461,6 +471,7 @@ int reduce_max(gpbo_ctx* ctx, const double* a, int64_t m, double* dst_dev) {
 int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     if (!ctx->fitted) BADARG("posterior: no fitted model");
     if (ctx->m <= 0 || !ctx->Xs) BADARG("posterior: no candidates");
+    if (ctx->m != ctx->xs_rows) BADARG("posterior: the resident posterior was uploaded with gpbo_set_posterior; call gpbo_set_candidates first");
     CHK(ensure_scratch(ctx));
     const bool keep_v = (ctx->variant == GPBO_VARIANT_SINGLE && ctx->reserve > 0 && ctx->have_factor);   // also after the last append
     if (keep_v) {
@@ -479,9 +490,30 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     int mode = 2;   // tile engine scheduling: priority raise over the MFMA bursts + fragment prefetch
     if (const char* e = getenv("GPBO_TRMM_MODE")) mode = atoi(e);
     double trmm_launches = 0;
+    double ms[T_NCAT], cnt[T_NCAT], ms_acc[T_NCAT];
+    for (int i = 0; i < T_NCAT; ++i) ms_acc[i] = 0;
+    // Long sweeps are cut into segments of SEG chunks: at a segment boundary the stream is drained, the event pool
+    // recycled (six events per chunk otherwise pile up: 16384 chunks at n = 32768 and 64 M candidates) and, with
+    // GPBO_PROGRESS=1, one line goes to stderr.  A boundary costs one idle gap of a few microseconds.
+    const int64_t SEG = 512;
+    const bool progress = getenv("GPBO_PROGRESS") && atoi(getenv("GPBO_PROGRESS")) != 0;
+    const int64_t nchunks = (ctx->m + ctx->chunk - 1) / ctx->chunk;
+    const auto wall0 = std::chrono::steady_clock::now();
     {
-        Scope tot(ctx, T_TOTAL);
-        for (int64_t j0 = 0; j0 < ctx->m; j0 += ctx->chunk) {
+        std::unique_ptr<Scope> tot(new Scope(ctx, T_TOTAL));      // start-to-end time of a segment, launch gaps included
+        int64_t ci = 0;
+        for (int64_t j0 = 0; j0 < ctx->m; j0 += ctx->chunk, ++ci) {
+            if (ci > 0 && ci % SEG == 0) {
+                tot.reset();
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                timing_collect(ctx, ms, cnt);
+                for (int i = 0; i < T_NCAT; ++i) ms_acc[i] += ms[i];
+                timing_begin(ctx);
+                if (progress)
+                    fprintf(stderr, "[gpbo] posterior: chunk %lld of %lld, %.1f s\n", (long long)ci, (long long)nchunks,
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count());
+                tot.reset(new Scope(ctx, T_TOTAL));
+            }
             const int64_t cols = std::min<int64_t>(ctx->chunk, round_up(ctx->m - j0, 256));   // multiple of 256
             {
                 Scope s(ctx, T_KS);
@@ -521,13 +553,13 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     double mu_max = 0;
     HIPCHK(hipMemcpyAsync(&mu_max, ctx->inc_dev + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    double ms[T_NCAT], cnt[T_NCAT];
     timing_collect(ctx, ms, cnt);
-    ctx->tm.posterior_total_ms = ms[T_TOTAL];
-    ctx->tm.ksbuild_ms = ms[T_KS];
-    ctx->tm.trmm_ms = ms[T_TRMM];
+    for (int i = 0; i < T_NCAT; ++i) ms_acc[i] += ms[i];
+    ctx->tm.posterior_total_ms = ms_acc[T_TOTAL];
+    ctx->tm.ksbuild_ms = ms_acc[T_KS];
+    ctx->tm.trmm_ms = ms_acc[T_TRMM];
     ctx->tm.trmm_launches = trmm_launches;
-    ctx->tm.finalize_ms = ms[T_FIN];
+    ctx->tm.finalize_ms = ms_acc[T_FIN];
     ctx->tm.trmm_flops = (double)ctx->n * (double)ctx->n * (double)ctx->m;
     ctx->have_posterior = true;
     ctx->inc_valid = keep_v;
@@ -554,7 +586,7 @@ int append_impl(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max
     if (!ctx->fitted || !ctx->have_factor) BADARG("append: no fitted model with a factor on this context");
     if (ctx->variant != GPBO_VARIANT_SINGLE) BADARG("append: only the single-factor variant can be updated incrementally");
     if (!x_new) BADARG("append: null x_new");
-    if (!ctx->inc_valid) BADARG("append: call gpbo_reserve_appends, gpbo_fit, gpbo_set_candidates and gpbo_posterior first");
+    if (!ctx->inc_valid || ctx->m != ctx->xs_rows) BADARG("append: call gpbo_reserve_appends, gpbo_fit, gpbo_set_candidates and gpbo_posterior first");
     if (ctx->reserve_left <= 0 || ctx->n + 1 > ctx->n_pad || ctx->n + 1 > ctx->v_cap_rows) BADARG("append: reserved rows exhausted (gpbo_reserve_appends)");
     const int n = (int)ctx->n;
     const long ld = ctx->n_pad;
@@ -655,8 +687,8 @@ int acquire_impl(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumben
     return GPBO_OK;
 }
 
-int set_candidates_impl(gpbo_ctx* ctx, const double* Xs, int64_t m, int on_device) {
-    if (!Xs || m <= 0) BADARG("set_candidates: empty candidate set");
+int reserve_candidates(gpbo_ctx* ctx, int64_t m) {
+    if (m <= 0) BADARG("set_candidates: empty candidate set");
     if (!ctx->fitted) BADARG("set_candidates: fit first (the candidate width is the model's d)");
     if (m * ctx->d > ctx->xs_cap) {
         CHK(dev_alloc(ctx, &ctx->Xs, (size_t)m * ctx->d));
@@ -669,8 +701,15 @@ int set_candidates_impl(gpbo_ctx* ctx, const double* Xs, int64_t m, int on_devic
         ctx->m_cap = m;
     }
     ctx->m = m;
+    ctx->xs_rows = m;
     ctx->have_posterior = false;
     ctx->inc_valid = false;
+    return GPBO_OK;
+}
+
+int set_candidates_impl(gpbo_ctx* ctx, const double* Xs, int64_t m, int on_device) {
+    if (!Xs) BADARG("set_candidates: null candidate pointer");
+    CHK(reserve_candidates(ctx, m));
     HIPCHK(hipMemcpyAsync(ctx->Xs, Xs, (size_t)m * ctx->d * sizeof(double),
                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -765,7 +804,7 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = round_up(n + (variant == GPBO_VARIANT_SINGLE ? ctx->reserve : 0), PB);
     CHK(ensure_model(ctx, n_pad, d, true));
-    if (d != ctx->d) ctx->m = 0;   // resident candidates have the old column count: dropped
+    if (d != ctx->d) ctx->m = ctx->xs_rows = 0;   // resident candidates have the old column count: dropped
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->inc_valid = false;
@@ -855,6 +894,19 @@ int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xs, int64_t m, int32_t on_d
     if (!ctx) return GPBO_ERR_BAD_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     return set_candidates_impl(ctx, Xs, m, on_device);
+}
+
+int gpbo_set_candidates_uniform(gpbo_ctx* ctx, uint64_t seed, int64_t row_offset, int64_t m) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (row_offset < 0) BADARG("set_candidates_uniform: negative row offset");
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(reserve_candidates(ctx, m));
+    const long count = (long)m * ctx->d;
+    hipLaunchKernelGGL(k_uniform_splitmix, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xs, count,
+                       (unsigned long long)seed, (unsigned long long)row_offset * (unsigned long long)ctx->d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GPBO_OK;
 }
 
 int gpbo_posterior(gpbo_ctx* ctx, double* mu_max_out) {
@@ -959,13 +1011,14 @@ int gpbo_state_describe(gpbo_ctx* ctx, gpbo_state_desc* out) {
     return GPBO_OK;
 }
 
-int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int32_t d, int32_t kernel, int32_t variant, double sigmaY) {
+int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int64_t n_pad_in, int32_t d, int32_t kernel, int32_t variant, double sigmaY) {
     if (!ctx) return GPBO_ERR_BAD_ARG;
     if (n <= 0 || d <= 0 || d > MAX_D) BADARG("state_alloc: bad shape");
+    if (n_pad_in != 0 && (n_pad_in < n || n_pad_in % PB != 0)) BADARG("state_alloc: n_pad must be 0 or a multiple of 128 that is >= n");
     HIPCHK(hipSetDevice(ctx->device));
-    const int64_t n_pad = round_up(n, PB);
+    const int64_t n_pad = n_pad_in ? n_pad_in : round_up(n, PB);   // the sender's padding (it may hold rows reserved for appends)
     if (n_pad != ctx->cap_pad) CHK(ensure_model(ctx, n_pad, d, false));
-    if (d != ctx->d) ctx->m = 0;
+    if (d != ctx->d) ctx->m = ctx->xs_rows = 0;
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->have_factor = false;
@@ -1016,7 +1069,7 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = round_up(n, PB);
     CHK(ensure_model(ctx, n_pad, d, true));
-    if (d != ctx->d) ctx->m = 0;
+    if (d != ctx->d) ctx->m = ctx->xs_rows = 0;
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->inc_valid = false;
@@ -1370,7 +1423,8 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
 
     // The settings are independent.  Each lane = a context of its own (work matrices + stream); settings are dealt
     // round-robin over the lanes so that the latency-bound parts of one factorisation (diagonal blocks, panel
-    // solves, triangular solves) overlap the MFMA-bound updates of the others.  Lane 0 is the caller's context.
+    // solves, triangular solves) overlap the MFMA-bound updates of the others.  Every lane is a private work context:
+    // the caller's own model, candidates and posterior are never touched by a likelihood sweep.
     // Eight lanes measure 5-6 % faster than four at n = 16384; a lane holds three n_pad^2 matrices, so large problems
     // take as many as fit in half of the free memory.
     int lanes = 8;
@@ -1408,7 +1462,6 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         use_graph = false;
     }
     std::vector<gpbo_ctx*> lane(lanes, nullptr);
-    lane[0] = ctx;
     if (lockstep) {
         if (!ctx->lml_lock && gpbo_create(ctx->device, &ctx->lml_lock) != GPBO_OK) {
             ctx->err = "lml_batch: could not create the batched work context";
@@ -1424,7 +1477,8 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         lane[0]->bs.gp = (long)ntiles * GRAD_D;
         lane[0]->bs.slot = (long)(sizeof(LmlSlot) / sizeof(double));
     }
-    for (int l = 1; l < lanes && l - 1 < (int)ctx->lml_lanes.size(); ++l) lane[l] = ctx->lml_lanes[l - 1];
+    if (!lockstep)
+        for (int l = 0; l < lanes && l < (int)ctx->lml_lanes.size(); ++l) lane[l] = ctx->lml_lanes[l];
     auto fail_hip = [&](const char* what, hipError_t e) {
         ctx->err = std::string(what) + ": " + hipGetErrorString(e);
         ctx->lookahead = true;
@@ -1467,7 +1521,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         ctx->lb_bd_cap = cap;
     }
     for (int l = 0; l < lanes; ++l) {
-        if (l > 0 && !lane[l]) {
+        if (!lane[l]) {
             if (gpbo_create(ctx->device, &lane[l]) != GPBO_OK) {
                 ctx->err = "lml_batch: could not create a work context";
                 ctx->lookahead = true;
@@ -1478,8 +1532,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         gpbo_ctx* c = lane[l];
         int st = ensure_model(c, n_pad, d, true);
         if (st != GPBO_OK) {
-            if (l > 0) ctx->err = c->err;
-            ctx->lookahead = true;
+            ctx->err = c->err;
             return st;
         }
         c->lookahead = (lanes == 1) && !use_graph;   // several lanes already overlap each other's panel work
@@ -1500,6 +1553,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             c->slot_cap = 0;
             LCHK(hipMalloc((void**)&c->lane_slot, S * sizeof(LmlSlot)));
             c->slot_cap = S;
+            c->alloc_gen += 1;
         }
         if (c->params_cap < S * PARAMS_DOUBLES) {
             if (c->params) hipFree(c->params);
@@ -1507,6 +1561,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             c->params_cap = 0;
             LCHK(hipMalloc((void**)&c->params, S * PARAMS_DOUBLES * sizeof(double)));
             c->params_cap = S * PARAMS_DOUBLES;
+            c->alloc_gen += 1;
         }
         if (grad_out && c->lane_gpart_cap < (size_t)ntiles * GRAD_D * S) {
             if (c->lane_gpart) hipFree(c->lane_gpart);
@@ -1514,6 +1569,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             c->lane_gpart_cap = 0;
             LCHK(hipMalloc((void**)&c->lane_gpart, (size_t)ntiles * GRAD_D * 8 * S));
             c->lane_gpart_cap = (size_t)ntiles * GRAD_D * S;
+            c->alloc_gen += 1;
         }
     }
     {
@@ -1556,11 +1612,12 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     if (use_graph) {
         const std::vector<int64_t> key = {n, n_pad, d, kernel, grad_out ? 1 : 0, (int64_t)(intptr_t)ctx->lb_xraw,
                                           (int64_t)(intptr_t)ctx->lb_nll, (int64_t)(intptr_t)ctx->lb_grad,
-                                          (int64_t)(intptr_t)ctx->lb_info, 0};
+                                          (int64_t)(intptr_t)ctx->lb_info, (int64_t)(intptr_t)ctx->lb_th,
+                                          (int64_t)(intptr_t)ctx->lb_sg, 0};
         for (int l = 0; l < lanes; ++l) {
             gpbo_ctx* c = lane[l];
             std::vector<int64_t> k = key;
-            k.back() = (int64_t)(intptr_t)c->lane_gpart;
+            k.back() = c->alloc_gen;      // every buffer of the lane that the captured launches name (model, slot, params, partials)
             if (c->lane_graph && c->lane_graph_key == k) continue;
             if (c->lane_graph) {
                 hipGraphExecDestroy(c->lane_graph);
@@ -1617,7 +1674,6 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     if (grad_out) LCHK(hipMemcpy(grad_out, ctx->lb_grad, (size_t)B * d * 8, hipMemcpyDeviceToHost));
     LCHK(hipMemcpy(hinfo.data(), ctx->lb_info, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
 #undef LCHK
-    ctx->lookahead = true;               // lane 0 is the caller's context
     ctx->tm.fit_total_ms = wall_ms;      // host wall time of the whole sweep (several streams run concurrently)
     ctx->tm.chol_count = B;
     ctx->tm.kbuild_ms = ctx->tm.chol_ms = ctx->tm.trsv_ms = ctx->tm.inverse_ms = 0;
@@ -1677,6 +1733,13 @@ int gpbo_selftest_gemm(gpbo_ctx* ctx, int32_t n, double* err_out, double* rate_o
     for (auto& v : A) v = rnd();
     for (auto& v : B) v = rnd();
     double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    struct Guard {      // the three device matrices are released on every way out
+        double *&a, *&b, *&c;
+        ~Guard() {
+            for (double* p : {a, b, c})
+                if (p) hipFree(p);
+        }
+    } guard{dA, dB, dC};
     HIPCHK(hipMalloc((void**)&dA, nn * 8));
     HIPCHK(hipMalloc((void**)&dB, nn * 8));
     HIPCHK(hipMalloc((void**)&dC, nn * 8));
@@ -1717,9 +1780,6 @@ int gpbo_selftest_gemm(gpbo_ctx* ctx, int32_t n, double* err_out, double* rate_o
         hipEventDestroy(b);
         *rate_out = 2.0 * (double)n * n * n * reps / (ms * 1e-3) / 1e12;
     }
-    hipFree(dA);
-    hipFree(dB);
-    hipFree(dC);
     return GPBO_OK;
 }
 

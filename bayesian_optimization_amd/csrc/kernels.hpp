@@ -1606,6 +1606,21 @@ __global__ __launch_bounds__(256) void k_diag_minmax(const double* __restrict__ 
     }
 }
 
+// Synthetic candidates: element e of the row-major (m, d) set is the counter-based splitmix64 stream
+//   u(seed, e0 + e) = (mix(seed, e0 + e) >> 11) * 2^-53  in [0, 1),
+// integer arithmetic and an exact conversion, so a shard generated here is bit-identical to the same rows generated
+// on the host.  count = m * d elements.
+__global__ __launch_bounds__(256) void k_uniform_splitmix(double* __restrict__ out, long count, unsigned long long seed,
+                                                          unsigned long long e0) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    unsigned long long z = (e0 + (unsigned long long)e + 1ull) * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    out[e] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
 __global__ void k_set_scalar(double* dst, double v) { *dst = v; }
 __global__ void k_copy_scalar(double* dst, const double* src) { *dst = *src; }
 

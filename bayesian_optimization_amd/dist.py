@@ -90,17 +90,22 @@ def broadcast_model(gp, src: int = 0):
         return
     rank = dist.get_rank()
     xdev = _exchange_device(gp.device)
-    hdr = torch.zeros(8, dtype=torch.float64, device=xdev)
+    hdr = torch.zeros(9, dtype=torch.float64, device=xdev)
     if rank == src:
         sd = gp.state_desc()
-        hdr = torch.tensor([sd.n, sd.d, sd.kernel, sd.variant, sd.sigmaY, sd.y_max, gp.theta1, gp.nll],
+        hdr = torch.tensor([sd.n, sd.d, sd.kernel, sd.variant, sd.sigmaY, sd.y_max, gp.theta1, gp.nll, sd.n_pad],
                            dtype=torch.float64, device=xdev)
     dist.broadcast(hdr, src)
+    hdr = hdr.cpu()
     n, d, kernel, variant = (int(hdr[i].item()) for i in range(4))
-    sigmaY, y_max = float(hdr[4].item()), float(hdr[5].item())
+    sigmaY, y_max, n_pad = float(hdr[4].item()), float(hdr[5].item()), int(hdr[8].item())
     if rank != src:
-        gp.state_alloc(n, d, kernel, variant, sigmaY)
-    tensors, _ = model_tensors(gp)
+        gp.state_alloc(n, d, kernel, variant, sigmaY, n_pad=n_pad)     # the sender's padding: it sizes every buffer below
+    tensors, sd_local = model_tensors(gp)
+    want = (8 * n_pad * n_pad, 8 * n_pad)
+    if (sd_local.W_bytes, sd_local.alpha_bytes) != want:
+        raise RuntimeError('broadcast_model: rank %d holds buffers of %r bytes, the sender\'s are %r' %
+                           (rank, (sd_local.W_bytes, sd_local.alpha_bytes), want))
     if dist.get_backend() == 'nccl':
         torch.cuda.synchronize(gp.device)
         for t in tensors:

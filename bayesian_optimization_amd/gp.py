@@ -104,6 +104,12 @@ class GP:
         self.m = int(m)
         return self
 
+    def set_candidates_uniform(self, seed: int, row_offset: int, m: int):
+        """Rows [row_offset, row_offset + m) of synth.uniform's candidate stream, generated in HBM."""
+        self._check(self._lib.gpbo_set_candidates_uniform(self._h, int(seed), int(row_offset), int(m)))
+        self.m = int(m)
+        return self
+
     def posterior(self):
         """Mean/variance for the resident candidates (kept in HBM); returns max(mu)."""
         mm = C.c_double()
@@ -233,8 +239,9 @@ class GP:
         self._check(self._lib.gpbo_state_describe(self._h, C.byref(sd)))
         return sd
 
-    def state_alloc(self, n, d, kernel, variant, sigmaY):
-        self._check(self._lib.gpbo_state_alloc(self._h, int(n), int(d), int(kernel), int(variant), float(sigmaY)))
+    def state_alloc(self, n, d, kernel, variant, sigmaY, n_pad=0):
+        """n_pad: the sender's padded size (StateDesc.n_pad); 0 = round_up(n, 128)."""
+        self._check(self._lib.gpbo_state_alloc(self._h, int(n), int(n_pad), int(d), int(kernel), int(variant), float(sigmaY)))
         self.n, self.d = int(n), int(d)
 
     def state_commit(self, y_max):

@@ -177,6 +177,9 @@ def hypopt_wrap(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain,
     """Signature of BayesOpt_v4.ipynb:180-186: the final iterate of the start with the lowest final cost."""
     param_cont, cost_cont, flag_cont = hypopt(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain, Daa, sigmaY, x0, kernel)
     ff = np.array([c[-1] if np.isfinite(c[-1]) else (c[-2] if len(c) > 1 else np.inf) for c in cost_cont])
+    if not np.isfinite(ff).any():
+        # every start sits where K is not positive definite: np.linalg.cholesky raises here in the reference (:161)
+        raise np.linalg.LinAlgError('hypopt_wrap: no start has a positive definite covariance matrix')
     iopt = int(np.argmin(ff))
     last = param_cont[iopt][-1] if np.isfinite(cost_cont[iopt][-1]) else param_cont[iopt][-2]
     return last

@@ -101,6 +101,12 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
  * and is copied device-to-device.  Replaces distmat_v2(xTest,xTrain) inputs (:132). */
 int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xs, int64_t m, int32_t on_device);
 
+/* A synthetic candidate set generated in HBM: rows [row_offset, row_offset + m) of the (.., d) set whose element e
+ * (row-major) is the counter-based splitmix64 uniform u(seed, e) in [0,1) -- the same numbers, bit for bit, as
+ * bayesian_optimization_amd/synth.py:uniform on the host.  Stands where the notebooks build their candidate grid on
+ * the host (BayesOpt_v4.ipynb:705-714) for benchmark sets too large to generate and upload (64 M x 8 = 4.3 GB). */
+int gpbo_set_candidates_uniform(gpbo_ctx* ctx, uint64_t seed, int64_t row_offset, int64_t m);
+
 /* Pass 1 over the resident candidates: posterior mean and variance
  * (BayesOpt_v4.ipynb:135,146,149-151; only diag(Cov) is formed) kept in HBM, and the
  * maximum posterior mean of this context's candidates (:193). */
@@ -139,7 +145,9 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
                      int32_t deg, double* beta_out, int32_t* nbeta_out, double* cov_out);
 
 /* Make host arrays (m,) the resident posterior, so gpbo_acquire can run expected_improvement
- * (BayesOpt_v4.ipynb:188-197) / acquisition (Gaussian_Process_Regression.ipynb:265-268) on any Mu, diag(Cov). */
+ * (BayesOpt_v4.ipynb:188-197) / acquisition (Gaussian_Process_Regression.ipynb:265-268) on any Mu, diag(Cov).
+ * The resident candidates no longer describe this posterior: unless m equals their row count, gpbo_posterior and
+ * gpbo_append return GPBO_ERR_BAD_ARG until gpbo_set_candidates is called again. */
 int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64_t m);
 
 /* kernfcn_v2(distmat_v2(U,V), theta) (BayesOpt_v4.ipynb:100-105,119-124): the (p,q) covariance matrix
@@ -159,7 +167,8 @@ int gpbo_reserve_appends(gpbo_ctx* ctx, int64_t max_appends);
 /* -logL (mlefcn, BayesOpt_v4.ipynb:154-165) and, when grad_out != NULL, its gradient
  * w.r.t. theta (jacmlefun, GP/BayesOpt_v3.m:392-417; the Matern-5/2 form has no reference counterpart) for B settings.
  * thetas is (B,d), sigmas (B,), nll_out (B,), grad_out (B,d).  status_out (B,) may be
- * NULL; a non-PD setting yields nll = NaN and status GPBO_ERR_NOT_PD for that entry. */
+ * NULL; a non-PD setting yields nll = NaN and status GPBO_ERR_NOT_PD for that entry.
+ * The sweep runs in private work contexts owned by ctx: the model, candidates and posterior of ctx are untouched. */
 int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d,
                    const double* thetas, const double* sigmas, int32_t B, int32_t kernel,
                    double* nll_out, double* grad_out, int32_t* status_out);
@@ -182,7 +191,9 @@ int gpbo_cond_estimate(gpbo_ctx* ctx, double* cond_out);
  * other ranks need; they call gpbo_state_alloc() with the same shape, receive the
  * bytes into the described buffers (RCCL broadcast), then gpbo_state_commit(). */
 int gpbo_state_describe(gpbo_ctx* ctx, gpbo_state_desc* out);
-int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int32_t d, int32_t kernel, int32_t variant, double sigmaY);
+/* n_pad: the n_pad of the sender's gpbo_state_desc (a sender that reserved rows for appends pads further than
+ * round_up(n, 128), and every broadcast buffer is sized by it); 0 = round_up(n, 128). */
+int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int64_t n_pad, int32_t d, int32_t kernel, int32_t variant, double sigmaY);
 int gpbo_state_commit(gpbo_ctx* ctx, double y_max);
 
 /* Tuning knob: candidates per posterior chunk (multiple of 128; 0 = default). */
