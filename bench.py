@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the GP posterior + EI + argmax sweep (the hot path) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3] [--candidates M] [--n-train N]
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--candidates M] [--n-train N]
+                    [--scaling weak|strong]
 
-A step = one full pass over this rank's resident candidate block: K(X*,X) tiles, posterior mean,
-variance (W * Ks^T with fused column sum of squares on fp64 MFMA), max(Mu) [all-reduce], EI, argmax
-[all-gather].  The model is fitted once (rank 0) and broadcast before the timed region; candidates
-are resident in HBM.  value = candidates processed by all ranks / max-over-ranks time.
-Prints one JSON line on rank 0.
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) the script starts the N ranks itself, as fresh child
+processes of `python -m torch.distributed.run`, before anything in this process has touched the GPU; under a launcher
+it is one of the ranks.
+
+A step = one full pass over this rank's resident candidate block: K(X*,X) tiles, posterior mean, variance
+(W * Ks^T with fused column sum of squares on fp64 MFMA), max(Mu) [all-reduce], EI, argmax [all-gather].
+The model is fitted once (rank 0) and broadcast before the timed region; candidates are resident in HBM.
+value = candidates processed by all ranks / max-over-ranks time.  Rank 0 prints one JSON line.
+
+The default line measures BASELINE.json's 4096-point configuration (cfg2) and carries a second block, "cfg3", with the
+32768-point Matern-5/2 model of the 64 M-candidate configuration on a bounded slice of its candidates.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +30,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 flop/clk (v_mfma_f64_16x16x4: 2048 flop / 64 clk) x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def launch_ranks(n):
+    """Start n ranks of this script (same arguments) under torch.distributed.run and return its exit code.  Called before
+    torch or the HIP library is imported: this process never initialises the GPU, it only waits for the children."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(cfg, X, y, theta, Xs_sample):
@@ -50,7 +75,7 @@ def cpu_baseline(cfg, X, y, theta, Xs_sample):
                 fit_seconds=t_fit), st, (mu, var)
 
 
-def _dist_setup():
+def _dist_setup(need_gpu=True):
     """(world, rank, device index, backend).  GPBO_DIST_BACKEND=gloo and GPBO_FORCE_DEVICE=0 allow a multi-rank
     rehearsal on a single-GPU box; the default is one rank per GPU over nccl (= RCCL)."""
     import torch
@@ -60,7 +85,8 @@ def _dist_setup():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dev = int(os.environ['GPBO_FORCE_DEVICE']) if 'GPBO_FORCE_DEVICE' in os.environ else local_rank
     backend = os.environ.get('GPBO_DIST_BACKEND', 'nccl')
-    torch.cuda.set_device(dev)
+    if need_gpu:
+        torch.cuda.set_device(dev)
     if world > 1:
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
@@ -77,6 +103,149 @@ def _max_over_ranks(dt, world, backend):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return dt
+
+
+def _ranks_seen(world):
+    import torch.distributed as dist
+    return dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
+
+
+def _profiled_traffic(config, n, cand_per_launch):
+    """HBM bytes per launch of the dominant kernel from a committed PMC pass of the same workload (separate --pmc
+    runs, FETCH_SIZE doubled as the gfx950 counter needs).  Never measured in this run: reported beside a null
+    roofline.traffic, with the file it comes from."""
+    for name in ('r2_%s_traffic.json' % config, 'r1_%s_traffic.json' % config):
+        path = os.path.join(ROOT, 'profiles', name)
+        try:
+            tr = json.load(open(path))
+            if tr['n_train'] == n and abs(cand_per_launch - tr['candidates_per_launch']) < 1:
+                return {'bytes_per_launch': tr['fetch_bytes_per_launch'] + tr['write_bytes_per_launch'], 'source': 'profiles/' + name}
+        except Exception:
+            continue
+    return None
+
+
+def sweep_block(a, config, gp, world, rank, backend, steps, warmup, with_cpu):
+    """Fit (rank 0) -> broadcast -> resident candidates -> `warmup` + `steps` sweeps.  Returns the result dict on rank 0."""
+    import torch
+    import torch.distributed as dist
+    from bayesian_optimization_amd import synth
+    from bayesian_optimization_amd import dist as gdist
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cfg = dict(synth.CONFIGS[config])
+    if a.n:
+        cfg['n'] = a.n
+    strong = a.scaling == 'strong'
+    if strong:
+        m_total = a.m if a.m else cfg['m']
+        lo, hi = gdist.shard_range(m_total, rank, world)
+    else:
+        m_per_gpu = a.m if a.m else cfg['m']
+        if config == 'cfg3' and not a.m:
+            m_per_gpu = 1 << 17 if a.config != 'cfg3' else 1 << 18      # a bounded slice per GPU (stated in config.workload)
+        lo, hi = rank * m_per_gpu, (rank + 1) * m_per_gpu
+        m_total = world * m_per_gpu
+    m_local = hi - lo
+
+    X, y, theta = synth.training_set(cfg)
+    fit_tm, cond_est, fit_wall = None, None, 0.0
+    barrier()
+    t0 = time.perf_counter()
+    if rank == 0:
+        gp.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
+        fit_tm = gp.timings()
+        fit_wall = time.perf_counter() - t0
+        cond_est = gp.cond_estimate()
+    barrier()
+    t0 = time.perf_counter()
+    gdist.broadcast_model(gp, 0)
+    barrier()
+    bcast_s = _max_over_ranks(time.perf_counter() - t0, world, backend) if world > 1 else 0.0
+    t0 = time.perf_counter()
+    gp.set_candidates_uniform(cfg['seed_c'], lo, m_local)          # generated in HBM: same numbers as synth.candidates(cfg, lo, hi)
+    cand_s = time.perf_counter() - t0
+    sweep = gdist.ShardedSweep(gp, offset=lo)
+
+    for _ in range(warmup):
+        sweep.step(0, cfg['kappa'])
+    barrier()
+    t0 = time.perf_counter()
+    trmm_ms = trmm_launches = ks_ms = post_ms = acq_ms = 0.0
+    for _ in range(steps):
+        gidx, gbest, mu_max = sweep.step(0, cfg['kappa'])
+        tm = gp.timings()                      # HIP-event times on the library's own stream, per step
+        trmm_ms += tm['trmm_ms']
+        trmm_launches += tm['trmm_launches']
+        ks_ms += tm['ksbuild_ms']
+        post_ms += tm['posterior_total_ms']
+        acq_ms += tm['acquire_ms']
+    barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, world, backend)
+    if rank != 0:
+        return None
+
+    n = cfg['n']
+    total = m_total * steps
+    cand_per_launch = m_local * steps / max(trmm_launches, 1)
+    flops_per_launch = float(n) * n * cand_per_launch             # n^2 per candidate x candidates per launch
+    avg_launch_s = trmm_ms * 1e-3 / max(trmm_launches, 1)
+    achieved = flops_per_launch / avg_launch_s / 1e12
+    prof = _profiled_traffic(config, n, cand_per_launch)
+    out = {
+        'metric': 'gp_posterior_ei_candidates_per_sec', 'value': total / dt, 'unit': 'candidates/s',
+        'n_gpus': world, 'ranks_seen': _ranks_seen(world), 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
+        'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '%s: n=%d train, d=%d, %s, %s, sigmaY=%g, theta=%g, EI kappa=%g'
+                               % (config, n, cfg['d'], 'RBF' if cfg['kernel'] == 0 else 'Matern-5/2',
+                                  ('%d candidates split over %d GPUs' % (m_total, world)) if strong else
+                                  ('%d candidates per GPU (x%d GPUs)' % (m_local, world)),
+                                  cfg['sigmaY'], cfg['theta'], cfg['kappa']),
+                   'candidates_per_gpu': m_local, 'candidates_total': m_total, 'n_train': n, 'd': cfg['d'],
+                   'parallelism': 'candidate blocks per rank; all-reduce(max mu) + all-gather(argmax)'},
+        'roofline': {'bound': 'mfma', 'kernel': 'k_trmm_sumsq', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'traffic_source': ('not measured in this run; %s holds %.4g bytes per launch for this workload'
+                                        % (prof['source'], prof['bytes_per_launch'])) if prof else 'not measured in this run',
+                     'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3, 'launches': trmm_launches},
+        'phases_ms_per_step': {'posterior_total': post_ms / steps, 'ks_build': ks_ms / steps,
+                               'trmm_sumsq': trmm_ms / steps, 'acquire': acq_ms / steps},
+        'argmax': {'index': int(gidx), 'ei': gbest, 'mu_max': mu_max},
+    }
+    # every phase against its own bound, and the time-weighted combination over the sweep
+    ks_s, other_s = ks_ms * 1e-3, max(post_ms + acq_ms - ks_ms - trmm_ms, 0.0) * 1e-3
+    cand = float(m_local * steps)
+    ks_gbs = 8.0 * n * cand / max(ks_s, 1e-12) / 1e9                   # the Ks panel: 8 n bytes written per candidate
+    other_gbs = (8.0 * cfg['d'] + 48.0) * cand / max(other_s, 1e-12) / 1e9   # read x*, write mu/var/ei, EI pass re-reads mu/var
+    ph = [('trmm_sumsq', 'mfma', trmm_ms * 1e-3, achieved / FP64_MFMA_PEAK_TFLOPS),
+          ('ks_build', 'hbm', ks_s, ks_gbs / HBM_PEAK_GBS), ('finalize+acquire+reductions', 'hbm', other_s, other_gbs / HBM_PEAK_GBS)]
+    tsum = sum(t for _, _, t, _ in ph)
+    out['phase_rooflines'] = {'phases': [{'phase': k, 'bound': b, 'ms_per_step': t / steps * 1e3, 'frac': f} for k, b, t, f in ph],
+                              'time_weighted_frac': sum(t * f for _, _, t, f in ph) / max(tsum, 1e-12)}
+    nchol = max(fit_tm['chol_count'], 1)
+    out['fit'] = {'total_ms': fit_tm['fit_total_ms'], 'wall_ms': fit_wall * 1e3, 'cholesky_ms_each': fit_tm['chol_ms'] / nchol,
+                  'cholesky_gflops': (n ** 3 / 3.0) / (fit_tm['chol_ms'] / nchol * 1e-3) / 1e9,
+                  'inverse_ms': fit_tm['inverse_ms'], 'trsv_ms': fit_tm['trsv_ms'], 'kbuild_ms': fit_tm['kbuild_ms'],
+                  'cond_estimate': cond_est}
+    sweep_s = dt / steps
+    out['end_to_end'] = {'fit_ms': fit_wall * 1e3, 'broadcast_ms': bcast_s * 1e3, 'candidates_ms': cand_s * 1e3,
+                         'sweep_ms': sweep_s * 1e3,
+                         'broadcast_bytes': 8.0 * ((-(-n // 128) * 128) ** 2) if world > 1 else 0.0,
+                         'candidates_per_sec_incl_fit_and_broadcast': m_total / (fit_wall + bcast_s + sweep_s)}
+    if with_cpu:
+        ns = 16384 if n <= 8192 else 2048
+        Xs = synth.candidates(cfg, lo, lo + ns)
+        base, st, (mu_o, var_o) = cpu_baseline(cfg, X, y, theta, Xs)
+        out['cpu_baseline'] = base
+        mu, var = gp.read(offset=0, count=ns)
+        rel = lambda p, q: float(np.max(np.abs(p - q)) / np.max(np.abs(q)))
+        out['parity_vs_oracle'] = {'sample': ns, 'mean_relmax': rel(mu, mu_o), 'var_relmax': rel(var, var_o)}
+    return out
 
 
 def secondary(a):
@@ -141,6 +310,7 @@ def secondary(a):
             loops = 1 if sharded else world
             print(json.dumps({
                 'metric': 'bo_loop_iterations_per_sec', 'value': loops * iters / dt, 'unit': 'iterations/s', 'n_gpus': world,
+                'ranks_seen': _ranks_seen(world),
                 'steps': iters, 'warmup': a.warmup, 'ms_per_step': dt / iters * 1e3, 'higher_is_better': True,
                 'scaling': 'strong' if sharded else 'weak',
                 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -149,11 +319,11 @@ def secondary(a):
                                        % (iters, side, m_total, n0, 'candidate rows and resident V split over the GPUs, one loop'
                                           if sharded else 'one independent loop per GPU'),
                            'n_final': gp.n, 'best_y': float(gp.y_max), 'picked_head': [int(j) for j in picked[:16]]},
-                'roofline': {'bound': 'hbm', 'kernel': 'k_append_sweep', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                             'frac': achieved / 8000.0, 'traffic': None, 'avg_launch_ms': sweep_ms / iters,
+                'roofline': {'bound': 'hbm', 'kernel': 'k_append_sweep', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': sweep_ms / iters,
                              'bytes_per_launch_avg': bytes_alg / iters}}), flush=True)
     else:
-        n, d = 16384, 8
+        n, d = (a.n or 16384), 8
         Btot = 256
         per = a.settings if a.settings else max(1, Btot // world)
         X = synth.uniform(5, n * d).reshape(n, d)
@@ -177,6 +347,7 @@ def secondary(a):
             achieved = flops / dt / 1e12 / world
             print(json.dumps({
                 'metric': 'lml_grad_settings_per_sec', 'value': world * per * a.steps / dt, 'unit': 'settings/s', 'n_gpus': world,
+                'ranks_seen': _ranks_seen(world),
                 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                 'config': {'workload': 'cfg5: -logL + analytic gradient, n=%d, d=%d, RBF, %d settings per GPU (16 length-scale multipliers x 16 sigmaY)' % (n, d, per),
@@ -189,132 +360,76 @@ def secondary(a):
         dist.destroy_process_group()
 
 
+def rehearse(a):
+    """Launch plumbing only, no GPU: the ranks rendezvous (gloo), split a candidate range and run the sweep's two exchange
+    steps on stand-in local results (tests/_standin_gp.py).  Lets a CPU-only machine check that --gpus N really runs N ranks."""
+    import torch.distributed as dist
+    from bayesian_optimization_amd import dist as gdist
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from _standin_gp import StandinGP
+    os.environ.setdefault('GPBO_DIST_BACKEND', 'gloo')
+    world, rank, _, backend = _dist_setup(need_gpu=False)
+    m_total = a.m if a.m else 1000
+    lo, hi = gdist.shard_range(m_total, rank, world)
+    sweep = gdist.ShardedSweep(StandinGP(lo, hi), offset=lo)
+    gidx, gbest, mu_max = sweep.step(0, 0.01)
+    if rank == 0:
+        print(json.dumps({'rehearsal': True, 'n_gpus': world, 'ranks_seen': _ranks_seen(world), 'backend': backend,
+                          'argmax': {'index': int(gidx), 'ei': gbest, 'mu_max': mu_max}, 'value': None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='cfg2')
-    ap.add_argument('--candidates', dest='m', type=int, default=0, help='candidates per GPU (default: the config\'s m)')
+    ap.add_argument('--candidates', dest='m', type=int, default=0,
+                    help='candidates per GPU (weak scaling) or in total (strong scaling); default: the config\'s m')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: every rank sweeps the same number of candidates; strong: the set is split over the ranks')
     ap.add_argument('--n-train', dest='n', type=int, default=0, help='training points (default: the config\'s n)')
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cfg3', action='store_true', help='leave the 32768-point block out of the default line')
     ap.add_argument('--iters', type=int, default=200, help='cfg4: EI iterations')
     ap.add_argument('--side', type=int, default=64, help='cfg4: points per axis of the candidate lattice')
     ap.add_argument('--replicas', action='store_true', help='cfg4 with several GPUs: independent loops instead of one sharded loop')
     ap.add_argument('--settings', type=int, default=0, help='cfg5: settings per GPU (default 256 / gpus)')
+    ap.add_argument('--rehearse', action='store_true', help='launch/exchange plumbing only, on the CPU (no GPU work, no measurement)')
     a = ap.parse_args()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != a.gpus:
+        print('bench.py: --gpus %d but the launcher started %s ranks; reporting the launcher\'s count'
+              % (a.gpus, os.environ['WORLD_SIZE']), file=sys.stderr)
     if os.environ.get('GPBO_STALL_DUMP'):      # diagnosis: dump every thread's Python stack if the run is still going after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['GPBO_STALL_DUMP']), exit=False)
+    if a.rehearse:
+        return rehearse(a)
     if a.config in ('cfg4', 'cfg5'):
         return secondary(a)
 
-    import torch
     import torch.distributed as dist
-    from bayesian_optimization_amd import GP, synth
-    from bayesian_optimization_amd import dist as gdist
+    from bayesian_optimization_amd import GP
 
     world, rank, local_rank, backend = _dist_setup()
-
-    cfg = dict(synth.CONFIGS[a.config])
-    if a.n:
-        cfg['n'] = a.n
-    m_per_gpu = a.m if a.m else cfg['m']
-    if a.config == 'cfg3' and not a.m:
-        m_per_gpu = 1 << 18           # default run of the 32k configuration: a bounded slice per GPU (stated in config)
-    lo, hi = rank * m_per_gpu, (rank + 1) * m_per_gpu       # weak scaling: every rank sweeps m_per_gpu candidates
-
     gp = GP(local_rank)
     if a.chunk:
         gp.set_chunk(a.chunk)
-    X, y, theta = synth.training_set(cfg)
-    fit_tm = None
+    out = sweep_block(a, a.config, gp, world, rank, backend, a.steps, a.warmup, with_cpu=(world == 1 and not a.no_cpu_baseline))
+    if a.config == 'cfg2' and not a.no_cfg3 and not a.n and not a.m:
+        # the 64 M-candidate configuration's model (n = 32768, d = 8, Matern-5/2) on a 131072-candidate slice per GPU; the
+        # CPU oracle is not run here (its fit alone takes over a minute): tests/ compare this model with the oracle
+        gp.set_chunk(0)
+        blk = sweep_block(a, 'cfg3', gp, world, rank, backend, steps=2, warmup=1, with_cpu=False)
+        if rank == 0:
+            out['cfg3'] = {k: blk[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'config', 'roofline',
+                                               'phases_ms_per_step', 'phase_rooflines', 'fit', 'end_to_end', 'argmax')}
     if rank == 0:
-        gp.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
-        fit_tm = gp.timings()
-        cond_est = gp.cond_estimate()
-    gdist.broadcast_model(gp, 0)
-    Xs = synth.candidates(cfg, lo, hi)
-    gp.set_candidates(Xs)
-    sweep = gdist.ShardedSweep(gp, offset=lo)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        sweep.step(0, cfg['kappa'])
-    barrier()
-    t0 = time.perf_counter()
-    trmm_ms = trmm_launches = ks_ms = post_ms = acq_ms = 0.0
-    for _ in range(a.steps):
-        gidx, gbest, mu_max = sweep.step(0, cfg['kappa'])
-        tm = gp.timings()                      # HIP-event times on the library's own stream, per step
-        trmm_ms += tm['trmm_ms']
-        trmm_launches += tm['trmm_launches']
-        ks_ms += tm['ksbuild_ms']
-        post_ms += tm['posterior_total_ms']
-        acq_ms += tm['acquire_ms']
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = _max_over_ranks(dt, world, backend)
-
-    if rank == 0:
-        n = cfg['n']
-        total = world * m_per_gpu * a.steps
-        flops_per_launch = float(n) * n * (m_per_gpu * a.steps / max(trmm_launches, 1))   # n^2 per candidate x candidates per launch
-        avg_launch_s = trmm_ms * 1e-3 / max(trmm_launches, 1)
-        achieved = flops_per_launch / avg_launch_s / 1e12
-        traffic = None
-        try:   # HBM bytes per launch of the dominant kernel, from the committed PMC passes of this same workload
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r1_cfg2_traffic.json')))
-            if tr['n_train'] == n and abs(m_per_gpu * a.steps / max(trmm_launches, 1) - tr['candidates_per_launch']) < 1:
-                traffic = tr['fetch_bytes_per_launch'] + tr['write_bytes_per_launch']
-        except Exception:
-            traffic = None
-        out = {
-            'metric': 'gp_posterior_ei_candidates_per_sec', 'value': total / dt, 'unit': 'candidates/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s: n=%d train, d=%d, %s, %d candidates per GPU (x%d GPUs), sigmaY=%g, theta=%g, EI kappa=%g'
-                                   % (a.config, n, cfg['d'], 'RBF' if cfg['kernel'] == 0 else 'Matern-5/2', m_per_gpu, world,
-                                      cfg['sigmaY'], cfg['theta'], cfg['kappa']),
-                       'candidates_per_gpu': m_per_gpu, 'n_train': n, 'd': cfg['d'],
-                       'parallelism': 'candidate blocks per rank; all-reduce(max mu) + all-gather(argmax)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_trmm_sumsq', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3,
-                         'launches': trmm_launches},
-            'phases_ms_per_step': {'posterior_total': post_ms / a.steps, 'ks_build': ks_ms / a.steps,
-                                   'trmm_sumsq': trmm_ms / a.steps, 'acquire': acq_ms / a.steps},
-            'argmax': {'index': int(gidx), 'ei': gbest, 'mu_max': mu_max},
-        }
-        # every phase against its own bound, and the time-weighted combination over the sweep
-        ks_s, other_s = ks_ms * 1e-3, max(post_ms + acq_ms - ks_ms - trmm_ms, 0.0) * 1e-3
-        cand = float(m_per_gpu * a.steps)
-        ks_gbs = 8.0 * n * cand / max(ks_s, 1e-12) / 1e9                   # the Ks panel: 8 n bytes written per candidate
-        other_gbs = (8.0 * cfg['d'] + 48.0) * cand / max(other_s, 1e-12) / 1e9   # read x*, write mu/var/ei, EI pass re-reads mu/var
-        ph = [('trmm_sumsq', 'mfma', trmm_ms * 1e-3, achieved / FP64_MFMA_PEAK_TFLOPS),
-              ('ks_build', 'hbm', ks_s, ks_gbs / 8000.0), ('finalize+acquire+reductions', 'hbm', other_s, other_gbs / 8000.0)]
-        tsum = sum(t for _, _, t, _ in ph)
-        out['phase_rooflines'] = {'phases': [{'phase': k, 'bound': b, 'ms_per_step': t / a.steps * 1e3, 'frac': f} for k, b, t, f in ph],
-                                  'time_weighted_frac': sum(t * f for _, _, t, f in ph) / max(tsum, 1e-12)}
-        if fit_tm:
-            nchol = max(fit_tm['chol_count'], 1)
-            out['fit'] = {'total_ms': fit_tm['fit_total_ms'], 'cholesky_ms_each': fit_tm['chol_ms'] / nchol,
-                          'cholesky_gflops': (n ** 3 / 3.0) / (fit_tm['chol_ms'] / nchol * 1e-3) / 1e9,
-                          'inverse_ms': fit_tm['inverse_ms'], 'trsv_ms': fit_tm['trsv_ms'], 'kbuild_ms': fit_tm['kbuild_ms'],
-                          'cond_estimate': cond_est}
-        if world == 1 and not a.no_cpu_baseline:
-            ns = 16384 if n <= 8192 else 2048
-            base, st, (mu_o, var_o) = cpu_baseline(cfg, X, y, theta, Xs[:ns])
-            out['cpu_baseline'] = base
-            mu, var = gp.read(offset=0, count=ns)
-            rel = lambda p, q: float(np.max(np.abs(p - q)) / np.max(np.abs(q)))
-            out['parity_vs_oracle'] = {'sample': ns, 'mean_relmax': rel(mu, mu_o), 'var_relmax': rel(var, var_o)}
         print(json.dumps(out), flush=True)
     gp.close()
     if world > 1:

@@ -28,13 +28,16 @@ def test_two_rank_sweep_equals_single_process(gp0):
     from bayesian_optimization_amd import synth
     m_per = 65536
     env = dict(os.environ, GPBO_DIST_BACKEND='gloo', GPBO_FORCE_DEVICE='0', MASTER_ADDR='127.0.0.1', GPBO_STALL_DUMP='60')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
-           '--candidates', str(m_per)]
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    # no launcher on the command line: --gpus 2 makes bench.py start its two ranks itself
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+           '--candidates', str(m_per), '--no-cfg3']
     out = _run(cmd, env, 'two_rank_sweep')
     line = [ln for ln in out.splitlines() if ln.startswith('{')][-1]
     res = json.loads(line)
-    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['candidates_per_gpu'] == m_per
+    assert res['n_gpus'] == 2 and res['ranks_seen'] == 2 and res['scaling'] == 'weak' and res['config']['candidates_per_gpu'] == m_per
+    assert res['end_to_end']['broadcast_ms'] > 0 and res['end_to_end']['fit_ms'] > 0
     cfg = synth.CONFIGS['cfg2']
     X, y, theta = synth.training_set(cfg)
     gp0.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
@@ -52,12 +55,13 @@ def test_two_rank_sharded_loop_picks_the_same_points(gp0):
     from bayesian_optimization_amd import synth, dist as gdist
     side, iters, d, n0 = 16, 12, 4, 16
     env = dict(os.environ, GPBO_DIST_BACKEND='gloo', GPBO_FORCE_DEVICE='0', MASTER_ADDR='127.0.0.1', GPBO_STALL_DUMP='60')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29543', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', 'cfg4', '--side', str(side),
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', 'cfg4', '--side', str(side),
            '--iters', str(iters), '--warmup', '0']
     out = _run(cmd, env, 'two_rank_loop')
     res = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
-    assert res['n_gpus'] == 2 and res['scaling'] == 'strong'
+    assert res['n_gpus'] == 2 and res['ranks_seen'] == 2 and res['scaling'] == 'strong'
     g1 = (np.arange(side) + 0.5) / side
     grid = np.stack(np.meshgrid(g1, g1, g1, g1, indexing='ij'), -1).reshape(-1, d)
     f = lambda x: np.exp(-8 * np.sum((x - 0.37) ** 2, -1)) + 0.5 * np.exp(-20 * np.sum((x - 0.8) ** 2, -1))
