@@ -1687,6 +1687,83 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
 
 }  // extern "C"
 
+// ---------------------------------------------------------------- acquisition without any allocation
+// gpbo_acquire_static: the kernels of gpbo_acquire (k_max_stage, k_acquire, k_argmax_stage) on caller-owned device
+// arrays, with the reduction partials in a file-scope device array instead of buffers a context allocates.
+namespace {
+constexpr int STATIC_BLOCKS = 1024;                        // first-stage workgroups of the two reductions
+constexpr int64_t STATIC_MAX_M = (int64_t)1 << 28;         // candidates per call (268,435,456)
+// layout (doubles): [0,1024) max partials | [1024,2048) argmax values | [2048,3072) argmax indices (int64)
+//                   [3072] incumbent  [3073] max(mu)  [3074] best value  [3075] best index (int64)
+constexpr int STATIC_SCRATCH_DOUBLES = 4096;               // 32 KiB per GPU, held until the process ends
+static __device__ __align__(256) double scratch[STATIC_SCRATCH_DOUBLES];
+constexpr int STATIC_MAX_DEVICES = 64;
+double* g_scratch_ptr[STATIC_MAX_DEVICES] = {};           // per device: the address of that GPU's copy of `scratch`
+std::mutex g_scratch_mutex;
+
+// The array's name is a host-side handle, not a device address: the address is looked up once per device, with that
+// device current, and only that pointer is ever given to kernels and copies.
+hipError_t static_scratch(int device, double** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        double* p = nullptr;
+        hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
+
+extern "C" int gpbo_acquire_static(int32_t device, void* stream, const double* mu_dev, const double* var_dev, int64_t m,
+                                   int32_t acq, double kappa, int32_t incumbent_mode, double incumbent, double* acq_out_dev,
+                                   int64_t* argmax_out, double* best_out, double* mu_max_out) {
+    if (!mu_dev || !var_dev || !acq_out_dev) return GPBO_ERR_BAD_ARG;
+    if (m <= 0 || m > STATIC_MAX_M) return GPBO_ERR_BAD_ARG;                 // beyond the stated maximum: rejected, nothing launched
+    if (acq < 0 || acq > 2) return GPBO_ERR_BAD_ARG;
+    if (incumbent_mode != GPBO_INCUMBENT_MAX_MU && incumbent_mode != GPBO_INCUMBENT_GIVEN) return GPBO_ERR_BAD_ARG;   // no model here: no max(yTrain)
+    if (device < 0 || device >= STATIC_MAX_DEVICES) return GPBO_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess) return GPBO_ERR_HIP;
+    double* sp = nullptr;
+    if (static_scratch(device, &sp) != hipSuccess) return GPBO_ERR_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    double* part_max = sp;
+    double* part_v = sp + STATIC_BLOCKS;
+    long* part_i = reinterpret_cast<long*>(sp + 2 * STATIC_BLOCKS);
+    double* inc = sp + 3 * STATIC_BLOCKS;
+    double* mu_max = inc + 1;
+    double* best_v = inc + 2;
+    long* best_i = reinterpret_cast<long*>(inc + 3);
+    const int blocks = (int)std::min<int64_t>(STATIC_BLOCKS, (m + 255) / 256);
+    // every scratch word read below is written first by this call (the stages write exactly `blocks` partials and the
+    // four scalars): nothing of an earlier call's contents is consumed, nothing needs clearing
+    hipLaunchKernelGGL(k_max_stage, dim3(blocks), dim3(256), 0, st, mu_dev, (long)m, part_max);
+    hipLaunchKernelGGL(k_max_stage, dim3(1), dim3(256), 0, st, (const double*)part_max, (long)blocks, mu_max);
+    if (incumbent_mode == GPBO_INCUMBENT_MAX_MU)
+        hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, st, inc, (const double*)mu_max);
+    else
+        hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, st, inc, incumbent);
+    hipLaunchKernelGGL(k_acquire, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, mu_dev, var_dev, (long)m, (int)acq, kappa,
+                       (const double*)inc, acq_out_dev);
+    hipLaunchKernelGGL(k_argmax_stage, dim3(blocks), dim3(256), 0, st, (const double*)acq_out_dev, (const long*)nullptr, (long)m,
+                       part_v, part_i);
+    hipLaunchKernelGGL(k_argmax_stage, dim3(1), dim3(256), 0, st, (const double*)part_v, (const long*)part_i, (long)blocks, best_v,
+                       best_i);
+    if (hipGetLastError() != hipSuccess) return GPBO_ERR_HIP;
+    double h[4] = {0, 0, 0, 0};      // incumbent, max(mu), best value, best index (bit pattern of an int64)
+    if (hipMemcpyAsync(h, inc, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return GPBO_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return GPBO_ERR_HIP;
+    long bi;
+    memcpy(&bi, &h[3], sizeof(bi));
+    if (bi == INT64_MAX) bi = 0;     // all NaN / -inf: numpy.argmax would also give the first element
+    if (argmax_out) *argmax_out = bi;
+    if (best_out) *best_out = h[2];
+    if (mu_max_out) *mu_max_out = h[1];
+    return GPBO_OK;
+}
+
 // ---------------------------------------------------------------- self test of the tile engine
 namespace {
 template <bool AK, bool BKC>

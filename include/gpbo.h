@@ -119,6 +119,21 @@ int gpbo_posterior(gpbo_ctx* ctx, double* mu_max_out);
 int gpbo_acquire(gpbo_ctx* ctx, int32_t acq, double kappa, int32_t incumbent_mode,
                  double incumbent, int64_t* argmax_out, double* best_out);
 
+/* The same acquisition pass for callers that cannot allocate: it has NO counterpart in the reference and exists for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  It needs no context and calls
+ * no hipMalloc / hipFree or any allocating routine: the partial results of its two reductions live in a 32 KiB
+ * file-scope device array that every GPU the library runs on holds until the process ends.
+ *   mu_dev, var_dev (m,) and acq_out_dev (m,) are DEVICE pointers owned by the caller; stream is a hipStream_t (NULL =
+ *   the default stream); argmax_out / best_out / mu_max_out are host pointers (any may be NULL), valid on return (the
+ *   call synchronises the stream).  incumbent_mode: GPBO_INCUMBENT_MAX_MU or GPBO_INCUMBENT_GIVEN (there is no model
+ *   here, so no max(yTrain)).  Same arithmetic and tie rule as gpbo_acquire: results are bit-identical.
+ * Limits: 1 <= m <= 2^28 (268,435,456) candidates per call, larger sizes return GPBO_ERR_BAD_ARG and launch nothing;
+ * device < 64.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two host threads,
+ * two streams) race and must be serialised by the caller. */
+int gpbo_acquire_static(int32_t device, void* stream, const double* mu_dev, const double* var_dev, int64_t m,
+                        int32_t acq, double kappa, int32_t incumbent_mode, double incumbent, double* acq_out_dev,
+                        int64_t* argmax_out, double* best_out, double* mu_max_out);
+
 /* Copy count results starting at candidate offset to host; any pointer may be NULL. */
 int gpbo_read(gpbo_ctx* ctx, double* mu, double* var, double* acq, int64_t offset, int64_t count);
 
