@@ -57,11 +57,13 @@ SIGNATURES = {
     'gpbo_set_candidates_uniform': (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64]),
     'gpbo_posterior': (C.c_int, [C.c_void_p, _dp]),
     'gpbo_acquire': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, _i64p, _dp]),
+    'gpbo_first_at_least': (C.c_int, [C.c_void_p, C.c_double, _i64p]),
     'gpbo_acquire_static': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32,
                                       C.c_double, C.c_void_p, _i64p, _dp, _dp]),
     'gpbo_read': (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int64, C.c_int64]),
     'gpbo_predict_ei': (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_double, C.c_int32, C.c_double, _dp, _dp, _dp, _i64p, _dp, _dp]),
     'gpbo_append': (C.c_int, [C.c_void_p, _dp, C.c_double, _dp]),
+    'gpbo_append_acquire': (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_int32, C.c_double, C.c_int32, C.c_double, _dp, _i64p, _dp]),
     'gpbo_kriging_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, C.c_double, C.c_int32, _dp, _i32p, _dp]),
     'gpbo_set_posterior': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
     'gpbo_kernel_matrix': (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, _dp]),

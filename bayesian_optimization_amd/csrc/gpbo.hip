@@ -93,6 +93,8 @@ struct gpbo_ctx {
     int64_t m = 0, m_cap = 0, xs_cap = 0;   // m_cap: outputs (doubles per array); xs_cap: doubles in Xs
     int64_t xs_rows = 0;                    // candidate rows resident in Xs (m may differ after gpbo_set_posterior)
     double *mu = nullptr, *var = nullptr, *acq = nullptr;
+    double *acq_pv = nullptr, *bmax = nullptr;   // per-workgroup partials: fused acquisition/argmax, max(mu) of the append sweep
+    long* acq_pi = nullptr;
     bool have_posterior = false;
 
     // chunk scratch
@@ -574,68 +576,120 @@ void launch_sweep_t(gpbo_ctx* ctx) {
         hipLaunchKernelGGL((k_append_sweep<D, 2>), dim3((unsigned)((ctx->m / 2 + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const double*)ctx->Xs, (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params,
                            (const double*)ctx->lvec, (const double*)ctx->scal, ctx->Vres, (long)ctx->m, (int)ctx->n, ctx->sres, ctx->mu,
-                           ctx->var, ctx->kernel);
+                           ctx->var, ctx->kernel, ctx->bmax);
     else
         hipLaunchKernelGGL((k_append_sweep<D, 1>), dim3((unsigned)((ctx->m + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const double*)ctx->Xs, (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params,
                            (const double*)ctx->lvec, (const double*)ctx->scal, ctx->Vres, (long)ctx->m, (int)ctx->n, ctx->sres, ctx->mu,
-                           ctx->var, ctx->kernel);
+                           ctx->var, ctx->kernel, ctx->bmax);
 }
 
-int append_impl(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out) {
+// ---- one BO-loop step in two halves: enqueue (launches only) and finish (one copy + one synchronisation), so that the
+// append and the acquisition that follows it can share a single host round trip (gpbo_append_acquire).
+int append_check(gpbo_ctx* ctx, const double* x_new) {
     if (!ctx->fitted || !ctx->have_factor) BADARG("append: no fitted model with a factor on this context");
     if (ctx->variant != GPBO_VARIANT_SINGLE) BADARG("append: only the single-factor variant can be updated incrementally");
     if (!x_new) BADARG("append: null x_new");
     if (!ctx->inc_valid || ctx->m != ctx->xs_rows) BADARG("append: call gpbo_reserve_appends, gpbo_fit, gpbo_set_candidates and gpbo_posterior first");
     if (ctx->reserve_left <= 0 || ctx->n + 1 > ctx->n_pad || ctx->n + 1 > ctx->v_cap_rows) BADARG("append: reserved rows exhausted (gpbo_reserve_appends)");
+    return GPBO_OK;
+}
+
+// factor update (O(n^2)) + the HBM-streaming sweep over the resident V with max(mu) folded into its epilogue.
+// Leaves max(mu) in inc_dev[1].  Call timing_begin first.
+int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new) {
     const int n = (int)ctx->n;
     const long ld = ctx->n_pad;
     ctx->h_xnew.assign(MAX_D, 0.0);
     for (int t = 0; t < ctx->d; ++t) ctx->h_xnew[t] = x_new[t] / ctx->theta[t];
     HIPCHK(hipMemcpyAsync(ctx->xnew_dev, ctx->h_xnew.data(), MAX_D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
-    timing_begin(ctx);
+    Scope tot(ctx, T_TOTAL);
+    hipLaunchKernelGGL(k_append_kvec, dim3((unsigned)((ctx->n_pad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xts, n,
+                       (int)ctx->n_pad, ctx->d, (const double*)ctx->xnew_dev, ctx->kvec, ctx->kernel);
+    hipLaunchKernelGGL(k_append_lvec, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const double*)ctx->bufW, ld, n,
+                       (const double*)ctx->kvec, ctx->lvec);
+    hipLaunchKernelGGL(k_append_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->lvec, ctx->zfw, ctx->yv, n,
+                       y_new, ctx->eps, ctx->scal, ctx->params, ctx->bufL, ctx->bufW, ld, ctx->info_dev);
+    hipLaunchKernelGGL(k_append_wrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufW, ld, n,
+                       (const double*)ctx->lvec, (const double*)ctx->scal);
+    hipLaunchKernelGGL(k_append_alpha, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double*)ctx->bufW, ld, n + 1, (const double*)ctx->zfw, ctx->alpha1, ctx->alpha);
     {
-        Scope tot(ctx, T_TOTAL);
-        hipLaunchKernelGGL(k_append_kvec, dim3((unsigned)((ctx->n_pad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xts, n,
-                           (int)ctx->n_pad, ctx->d, (const double*)ctx->xnew_dev, ctx->kvec, ctx->kernel);
-        hipLaunchKernelGGL(k_append_lvec, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const double*)ctx->bufW, ld, n,
-                           (const double*)ctx->kvec, ctx->lvec);
-        hipLaunchKernelGGL(k_append_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->lvec, ctx->zfw, ctx->yv, n,
-                           y_new, ctx->eps, ctx->scal, ctx->params, ctx->bufL, ctx->bufW, ld, ctx->info_dev);
-        hipLaunchKernelGGL(k_append_wrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufW, ld, n,
-                           (const double*)ctx->lvec, (const double*)ctx->scal);
-        hipLaunchKernelGGL(k_append_alpha, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const double*)ctx->bufW, ld, n + 1, (const double*)ctx->zfw, ctx->alpha1, ctx->alpha);
-        {
-            Scope sw(ctx, T_SWEEP);
-            switch (ctx->d) {
-                case 1: launch_sweep_t<1>(ctx); break;
-                case 2: launch_sweep_t<2>(ctx); break;
-                case 3: launch_sweep_t<3>(ctx); break;
-                case 4: launch_sweep_t<4>(ctx); break;
-                case 5: launch_sweep_t<5>(ctx); break;
-                case 6: launch_sweep_t<6>(ctx); break;
-                case 7: launch_sweep_t<7>(ctx); break;
-                case 8: launch_sweep_t<8>(ctx); break;
-                default: launch_sweep_t<0>(ctx); break;
-            }
+        Scope sw(ctx, T_SWEEP);
+        switch (ctx->d) {
+            case 1: launch_sweep_t<1>(ctx); break;
+            case 2: launch_sweep_t<2>(ctx); break;
+            case 3: launch_sweep_t<3>(ctx); break;
+            case 4: launch_sweep_t<4>(ctx); break;
+            case 5: launch_sweep_t<5>(ctx); break;
+            case 6: launch_sweep_t<6>(ctx); break;
+            case 7: launch_sweep_t<7>(ctx); break;
+            case 8: launch_sweep_t<8>(ctx); break;
+            default: launch_sweep_t<0>(ctx); break;
         }
-        CHK(reduce_max(ctx, ctx->mu, ctx->m, ctx->inc_dev + 1));
     }
+    // stage 2 of max(mu): one workgroup over the sweep's per-workgroup maxima
+    const long sweep_blocks = (ctx->m % 2 == 0) ? (ctx->m / 2 + 255) / 256 : (ctx->m + 255) / 256;
+    hipLaunchKernelGGL(k_max_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bmax, sweep_blocks, ctx->inc_dev + 1);
     HIPCHK(hipGetLastError());
-    double par_out[8], mu_max = 0;
-    int info = 0;
-    HIPCHK(hipMemcpyAsync(par_out, ctx->params, sizeof(par_out), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&mu_max, ctx->inc_dev + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return GPBO_OK;
+}
+
+// acquisition + argmax stage 1 fused, stage 2; results stay in red_v2 / red_i2.  store: keep the acquisition array.
+int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumbent, bool store) {
+    if (acq < 0 || acq > 2) BADARG("acquire: unknown acquisition");
+    Scope s(ctx, T_ACQ);
+    if (mode == GPBO_INCUMBENT_MAX_MU)
+        hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, (const double*)(ctx->inc_dev + 1));
+    else if (mode == GPBO_INCUMBENT_MAX_Y)
+        hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, (const double*)(ctx->params + P_YMAX));
+    else if (mode == GPBO_INCUMBENT_GIVEN)
+        hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, incumbent);
+    else
+        BADARG("acquire: unknown incumbent mode");
+    const unsigned blocks = (unsigned)((ctx->m + ACQ_SPAN - 1) / ACQ_SPAN);
+    if (store)
+        hipLaunchKernelGGL(k_acquire_argmax<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, (const double*)ctx->var,
+                           (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi);
+    else
+        hipLaunchKernelGGL(k_acquire_argmax<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, (const double*)ctx->var,
+                           (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi);
+    hipLaunchKernelGGL(k_argmax_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->acq_pv, (const long*)ctx->acq_pi,
+                       (long)blocks, ctx->red_v2, ctx->red_i2);
+    HIPCHK(hipGetLastError());
+    return GPBO_OK;
+}
+
+struct StepResult {      // what one synchronisation brings back
+    double par[8];
+    double mu_max, best;
+    long best_i;
+    int info;
+};
+
+int step_fetch(gpbo_ctx* ctx, StepResult* r, bool want_append, bool want_acquire) {
+    if (want_append) {
+        HIPCHK(hipMemcpyAsync(r->par, ctx->params, sizeof(r->par), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&r->info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&r->mu_max, ctx->inc_dev + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (want_acquire) {
+        HIPCHK(hipMemcpyAsync(&r->best, ctx->red_v2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&r->best_i, ctx->red_i2, sizeof(long), hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GPBO_OK;
+}
+
+int append_finish(gpbo_ctx* ctx, const StepResult& r, double* mu_max_out) {
     double ms[T_NCAT], cnt[T_NCAT];
     timing_collect(ctx, ms, cnt);
     ctx->tm.append_total_ms = ms[T_TOTAL];
     ctx->tm.append_sweep_ms = ms[T_SWEEP];
-    if (info != 0) {
-        ctx->info = info;
+    ctx->tm.acquire_ms = ms[T_ACQ];
+    if (r.info != 0) {
+        ctx->info = r.info;
         ctx->fitted = false;     // the factor row that was written is not usable
         ctx->inc_valid = false;
         ctx->err = "append: enlarged matrix is not positive definite";
@@ -643,47 +697,66 @@ int append_impl(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max
     }
     ctx->n += 1;
     ctx->reserve_left -= 1;
-    ctx->theta1 = par_out[P_THETA1];
-    ctx->nll = par_out[P_NLL];
-    ctx->y_max = par_out[P_YMAX];
-    if (mu_max_out) *mu_max_out = mu_max;
+    ctx->theta1 = r.par[P_THETA1];
+    ctx->nll = r.par[P_NLL];
+    ctx->y_max = r.par[P_YMAX];
+    if (mu_max_out) *mu_max_out = r.mu_max;
     return GPBO_OK;
+}
+
+int append_impl(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out) {
+    CHK(append_check(ctx, x_new));
+    timing_begin(ctx);
+    CHK(append_enqueue(ctx, x_new, y_new));
+    StepResult r{};
+    CHK(step_fetch(ctx, &r, true, false));
+    return append_finish(ctx, r, mu_max_out);
 }
 
 int acquire_impl(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumbent, int64_t* argmax_out, double* best_out) {
     if (!ctx->have_posterior) BADARG("acquire: no posterior (call gpbo_posterior first)");
-    if (acq < 0 || acq > 2) BADARG("acquire: unknown acquisition");
     timing_begin(ctx);
-    {
-        Scope s(ctx, T_ACQ);
-        if (mode == GPBO_INCUMBENT_MAX_MU)
-            hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, (const double*)(ctx->inc_dev + 1));
-        else if (mode == GPBO_INCUMBENT_MAX_Y)
-            hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, ctx->y_max);
-        else if (mode == GPBO_INCUMBENT_GIVEN)
-            hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, incumbent);
-        else
-            BADARG("acquire: unknown incumbent mode");
-        hipLaunchKernelGGL(k_acquire, dim3((unsigned)((ctx->m + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->mu,
-                           (const double*)ctx->var, (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq);
-        const int blocks = (int)std::min<int64_t>(1024, (ctx->m + 255) / 256);
-        hipLaunchKernelGGL(k_argmax_stage, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->acq, (const long*)nullptr,
-                           (long)ctx->m, ctx->red_v, ctx->red_i);
-        hipLaunchKernelGGL(k_argmax_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->red_v, (const long*)ctx->red_i,
-                           (long)blocks, ctx->red_v2, ctx->red_i2);
-    }
-    HIPCHK(hipGetLastError());
-    double bv = 0;
-    long bi = 0;
-    HIPCHK(hipMemcpyAsync(&bv, ctx->red_v2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&bi, ctx->red_i2, sizeof(long), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    CHK(acquire_enqueue(ctx, acq, kappa, mode, incumbent, true));
+    StepResult r{};
+    CHK(step_fetch(ctx, &r, false, true));
     double ms[T_NCAT], cnt[T_NCAT];
     timing_collect(ctx, ms, cnt);
     ctx->tm.acquire_ms = ms[T_ACQ];
-    if (bi == INT64_MAX) bi = 0;   // all NaN / -inf: numpy.argmax would also give the first element
-    if (argmax_out) *argmax_out = bi;
-    if (best_out) *best_out = bv;
+    if (r.best_i == INT64_MAX) r.best_i = 0;   // all NaN / -inf: numpy.argmax would also give the first element
+    if (argmax_out) *argmax_out = r.best_i;
+    if (best_out) *best_out = r.best;
+    return GPBO_OK;
+}
+
+// append + the acquisition over the updated posterior, one synchronisation.  The acquisition array is not stored
+// (gpbo_read(acq) after this call sees the values of the last gpbo_acquire).
+int append_acquire_impl(gpbo_ctx* ctx, const double* x_new, double y_new, int acq, double kappa, int mode, double incumbent,
+                        double* mu_max_out, int64_t* argmax_out, double* best_out) {
+    CHK(append_check(ctx, x_new));
+    if (acq < 0 || acq > 2) BADARG("append_acquire: unknown acquisition");
+    if (mode < 0 || mode > 2) BADARG("append_acquire: unknown incumbent mode");
+    timing_begin(ctx);
+    CHK(append_enqueue(ctx, x_new, y_new));
+    CHK(acquire_enqueue(ctx, acq, kappa, mode, incumbent, false));
+    StepResult r{};
+    CHK(step_fetch(ctx, &r, true, true));
+    CHK(append_finish(ctx, r, mu_max_out));
+    if (r.best_i == INT64_MAX) r.best_i = 0;
+    if (argmax_out) *argmax_out = r.best_i;
+    if (best_out) *best_out = r.best;
+    return GPBO_OK;
+}
+
+// mu / var / acq for m candidates and the per-workgroup partial arrays sized by m
+int ensure_outputs(gpbo_ctx* ctx, int64_t m) {
+    if (m <= ctx->m_cap) return GPBO_OK;
+    CHK(dev_alloc(ctx, &ctx->mu, m));
+    CHK(dev_alloc(ctx, &ctx->var, m));
+    CHK(dev_alloc(ctx, &ctx->acq, m));
+    CHK(dev_alloc(ctx, &ctx->acq_pv, (m + ACQ_SPAN - 1) / ACQ_SPAN));
+    CHK(dev_alloc(ctx, &ctx->acq_pi, (m + ACQ_SPAN - 1) / ACQ_SPAN));
+    CHK(dev_alloc(ctx, &ctx->bmax, (m + 255) / 256));
+    ctx->m_cap = m;
     return GPBO_OK;
 }
 
@@ -694,12 +767,7 @@ int reserve_candidates(gpbo_ctx* ctx, int64_t m) {
         CHK(dev_alloc(ctx, &ctx->Xs, (size_t)m * ctx->d));
         ctx->xs_cap = m * ctx->d;
     }
-    if (m > ctx->m_cap) {
-        CHK(dev_alloc(ctx, &ctx->mu, m));
-        CHK(dev_alloc(ctx, &ctx->var, m));
-        CHK(dev_alloc(ctx, &ctx->acq, m));
-        ctx->m_cap = m;
-    }
+    CHK(ensure_outputs(ctx, m));
     ctx->m = m;
     ctx->xs_rows = m;
     ctx->have_posterior = false;
@@ -761,7 +829,7 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     free_model(ctx);
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
                   ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
-                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres};
+                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres,     ctx->acq_pv,  ctx->acq_pi, ctx->bmax};
     for (void* p : ps)
         if (p) hipFree(p);
     for (auto e : ctx->pool) hipEventDestroy(e);
@@ -922,6 +990,23 @@ int gpbo_acquire(gpbo_ctx* ctx, int32_t acq, double kappa, int32_t incumbent_mod
     return acquire_impl(ctx, acq, kappa, incumbent_mode, incumbent, argmax_out, best_out);
 }
 
+int gpbo_first_at_least(gpbo_ctx* ctx, double threshold, int64_t* index_out) {
+    if (!ctx || !index_out) return GPBO_ERR_BAD_ARG;
+    if (!ctx->have_posterior) BADARG("first_at_least: no acquisition values (call gpbo_acquire first)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int blocks = (int)std::min<int64_t>(1024, (ctx->m + 255) / 256);
+    hipLaunchKernelGGL(k_first_ge_stage, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->acq, (const long*)nullptr,
+                       (long)ctx->m, threshold, ctx->red_i);
+    hipLaunchKernelGGL(k_first_ge_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)nullptr, (const long*)ctx->red_i,
+                       (long)blocks, threshold, ctx->red_i2);
+    HIPCHK(hipGetLastError());
+    long bi = 0;
+    HIPCHK(hipMemcpyAsync(&bi, ctx->red_i2, sizeof(long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *index_out = (bi == INT64_MAX) ? -1 : bi;
+    return GPBO_OK;
+}
+
 int gpbo_read(gpbo_ctx* ctx, double* mu, double* var, double* acq, int64_t offset, int64_t count) {
     if (!ctx) return GPBO_ERR_BAD_ARG;
     if (offset < 0 || count < 0 || offset + count > ctx->m) BADARG("read: range outside the candidate set");
@@ -1050,6 +1135,13 @@ int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max
     if (!ctx) return GPBO_ERR_BAD_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     return append_impl(ctx, x_new, y_new, mu_max_out);
+}
+
+int gpbo_append_acquire(gpbo_ctx* ctx, const double* x_new, double y_new, int32_t acq, double kappa, int32_t incumbent_mode,
+                        double incumbent, double* mu_max_out, int64_t* argmax_out, double* best_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    return append_acquire_impl(ctx, x_new, y_new, acq, kappa, incumbent_mode, incumbent, mu_max_out, argmax_out, best_out);
 }
 
 int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, double theta, int32_t deg,
@@ -1244,12 +1336,7 @@ int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64
     if (!ctx) return GPBO_ERR_BAD_ARG;
     if (!mu || !var || m <= 0) BADARG("set_posterior: empty input");
     HIPCHK(hipSetDevice(ctx->device));
-    if (m > ctx->m_cap) {
-        CHK(dev_alloc(ctx, &ctx->mu, m));
-        CHK(dev_alloc(ctx, &ctx->var, m));
-        CHK(dev_alloc(ctx, &ctx->acq, m));
-        ctx->m_cap = m;
-    }
+    CHK(ensure_outputs(ctx, m));
     ctx->m = m;
     ctx->inc_valid = false;
     HIPCHK(hipMemcpyAsync(ctx->mu, mu, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));

@@ -969,6 +969,28 @@ __global__ __launch_bounds__(256) void k_argmax_stage(const double* __restrict__
     }
 }
 
+// Lowest index i with a[i] >= thr (INT64_MAX if none); stage 1 over the array, stage 2 over the per-workgroup results.
+__global__ __launch_bounds__(256) void k_first_ge_stage(const double* __restrict__ a, const long* __restrict__ idx_in, long m,
+                                                        double thr, long* __restrict__ out_i) {
+    __shared__ long ri[256];
+    const int tid = threadIdx.x;
+    long bi = INT64_MAX;
+    for (long i = (long)blockIdx.x * 256 + tid; i < m; i += (long)gridDim.x * 256) {
+        if (idx_in) {
+            if (idx_in[i] < bi) bi = idx_in[i];
+        } else if (a[i] >= thr && i < bi) {
+            bi = i;
+        }
+    }
+    ri[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o && ri[tid + o] < ri[tid]) ri[tid] = ri[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) out_i[blockIdx.x] = ri[0];
+}
+
 // Standard normal CDF with the branch structure of Cephes ndtr (what scipy.stats.norm.cdf calls).
 __device__ __forceinline__ double ndtr_dev(double a) {
     const double x = a * 0.70710678118654752440;
@@ -979,25 +1001,73 @@ __device__ __forceinline__ double ndtr_dev(double a) {
     return y;
 }
 
+// One candidate's acquisition value: EI (BayesOpt_v4.ipynb:188-197, ei[sigma == 0] = 0), UCB (GP/BayesOpt_v1.m:248-251) or
+// PI (Gaussian_Process_Regression.ipynb:265-268).  Every kernel that evaluates an acquisition goes through this function,
+// so their results agree bit for bit.
+__device__ __forceinline__ double acq_value(double mj, double vj, double inc, int acq, double kappa) {
+    const double sigma = sqrt(vj);
+    if (acq == 0) {
+        const double imp = mj - inc - kappa;
+        const double Z = imp / sigma;
+        double r = imp * ndtr_dev(Z) + sigma * (exp(-Z * Z / 2.0) / 2.50662827463100050242);
+        if (sigma == 0.0) r = 0.0;
+        return r;
+    }
+    if (acq == 1) return mj + kappa * sigma;
+    return ndtr_dev((mj - inc) / sigma);
+}
+
 // Acquisition over the resident posterior.  inc_ptr: device scalar incumbent (EI/PI).
 __global__ __launch_bounds__(256) void k_acquire(const double* __restrict__ mu, const double* __restrict__ var, long m, int acq,
                                                  double kappa, const double* __restrict__ inc_ptr,
                                                  double* __restrict__ out) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
-    const double sigma = sqrt(var[j]);
-    double r;
-    if (acq == 0) {
-        const double imp = mu[j] - *inc_ptr - kappa;
-        const double Z = imp / sigma;
-        r = imp * ndtr_dev(Z) + sigma * (exp(-Z * Z / 2.0) / 2.50662827463100050242);
-        if (sigma == 0.0) r = 0.0;
-    } else if (acq == 1) {
-        r = mu[j] + kappa * sigma;
-    } else {
-        r = ndtr_dev((mu[j] - *inc_ptr) / sigma);
+    out[j] = acq_value(mu[j], var[j], *inc_ptr, acq, kappa);
+}
+
+// Acquisition and stage 1 of the first-occurrence argmax in one pass over (mu, var): a workgroup covers ACQ_SPAN
+// consecutive candidates, a thread ACQ_PER of them at stride 256 (coalesced), ascending, so "strictly greater" keeps the
+// lowest index; the workgroup's (value, index) goes to part_v / part_i.  STORE: also write the values to out.
+constexpr int ACQ_PER = 8;
+constexpr int ACQ_SPAN = 256 * ACQ_PER;
+template <bool STORE>
+__global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict__ mu, const double* __restrict__ var, long m, int acq,
+                                                        double kappa, const double* __restrict__ inc_ptr, double* __restrict__ out,
+                                                        double* __restrict__ part_v, long* __restrict__ part_i) {
+    __shared__ double rv[256];
+    __shared__ long ri[256];
+    const int tid = threadIdx.x;
+    const long base = (long)blockIdx.x * ACQ_SPAN;
+    const double inc = *inc_ptr;
+    double bv = -INFINITY;
+    long bi = INT64_MAX;
+#pragma unroll
+    for (int u = 0; u < ACQ_PER; ++u) {
+        const long j = base + u * 256 + tid;
+        if (j < m) {
+            const double r = acq_value(mu[j], var[j], inc, acq, kappa);
+            if (STORE) out[j] = r;
+            if (better(r, j, bv, bi)) {
+                bv = r;
+                bi = j;
+            }
+        }
     }
-    out[j] = r;
+    rv[tid] = bv;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o && better(rv[tid + o], ri[tid + o], rv[tid], ri[tid])) {
+            rv[tid] = rv[tid + o];
+            ri[tid] = ri[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part_v[blockIdx.x] = rv[0];
+        part_i[blockIdx.x] = ri[0];
+    }
 }
 
 
@@ -1454,9 +1524,11 @@ __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__
                                                       const double* __restrict__ xnew, const double* __restrict__ params,
                                                       const double* __restrict__ lvec, const double* __restrict__ scal,
                                                       double* __restrict__ V, long ldv, int n, double* __restrict__ sres,
-                                                      double* __restrict__ mu, double* __restrict__ var, int kernel) {
+                                                      double* __restrict__ mu, double* __restrict__ var, int kernel,
+                                                      double* __restrict__ bmax) {
     const long j = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
-    if (j >= m) return;
+    double mx = -INFINITY;           // the largest updated mean among this thread's candidates
+    if (j < m) {
     const int d = (D > 0) ? D : d_rt;
     double dot[VEC][8];
 #pragma unroll
@@ -1511,7 +1583,9 @@ __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__
         vout[c] = v;
         const double s = sres[j + c] + v * v;
         sres[j + c] = s;
-        mu[j + c] += v * znew;
+        const double mnew = mu[j + c] + v * znew;
+        mu[j + c] = mnew;
+        mx = fmax(mx, mnew);
         double vr = c0 - c1 * s;
         if (vr < 1e-60) vr = 0.0;
         var[j + c] = vr;
@@ -1524,6 +1598,13 @@ __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__
     } else {
         V[(long)n * ldv + j] = vout[0];
     }
+    }
+    // max(mu) of the workgroup's candidates (stage 1 of the reduction every iteration needs, free of a pass over mu)
+    __shared__ double wm[4];
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) bmax[blockIdx.x] = fmax(fmax(wm[0], wm[1]), fmax(wm[2], wm[3]));
 }
 
 

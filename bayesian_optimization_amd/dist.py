@@ -55,6 +55,15 @@ def global_argmax(local_best: float, local_index: int, offset: int, device=None)
     return pick_best(vals[:, 0], vals[:, 1].astype(np.int64))
 
 
+def global_first_at_least(gp, threshold, offset, fallback):
+    """Lowest GLOBAL index whose acquisition value is >= threshold (the tie-tolerant argmax once the global maximum is
+    known): each rank scans its block, one all-reduce(MAX) of the negated index picks the minimum."""
+    li = gp.first_at_least(threshold)
+    mine = float(li + int(offset)) if li >= 0 else float(2 ** 62)
+    g = -allreduce_max(-mine, gp.device)
+    return int(g) if g < 2 ** 62 else int(fallback)
+
+
 def pick_best(values, indices):
     values = np.asarray(values, dtype=np.float64)
     indices = np.asarray(indices, dtype=np.int64)
@@ -130,11 +139,13 @@ class ShardedSweep:
         self.gp = gp
         self.offset = int(offset)
 
-    def step(self, acq=0, kappa=0.01):
+    def step(self, acq=0, kappa=0.01, tie_rtol=0.0):
         mu_max_local = self.gp.posterior()
         mu_max = allreduce_max(mu_max_local, self.gp.device)
         idx, best = self.gp.acquire(acq, kappa, 2, mu_max)          # incumbent given = global max(Mu)
         gbest, gidx = global_argmax(best, idx, self.offset, self.gp.device)
+        if tie_rtol > 0.0 and np.isfinite(gbest):
+            gidx = global_first_at_least(self.gp, gbest - tie_rtol * abs(gbest), self.offset, gidx)
         return gidx, gbest, mu_max
 
 
@@ -172,6 +183,16 @@ class ShardedLoop:
     def observe(self, x_new, y_new):
         self.mu_max = allreduce_max(self.gp.append(x_new, y_new), self.gp.device)
         return self.mu_max
+
+    def step(self, x_new, y_new, acq=0, kappa=0.01):
+        """observe(x_new, y_new) then propose(acq, kappa): one loop iteration.  With a single rank the two halves share
+        one library call and one host synchronisation (the incumbent max(Mu) needs no exchange); the picks are the same."""
+        if _is_dist():
+            self.observe(x_new, y_new)
+            return self.propose(acq, kappa)
+        self.mu_max, idx, best = self.gp.append_acquire(x_new, y_new, acq, kappa, 0)      # incumbent = max(Mu), on the device
+        gidx = idx + self.offset
+        return gidx, best, self.X[idx].copy()
 
 
 def sharded_lml(gp, xTrain, yTrain, thetas, sigmas, kernel=0, grad=True):

@@ -116,12 +116,24 @@ class GP:
         self._check(self._lib.gpbo_posterior(self._h, C.byref(mm)))
         return mm.value
 
-    def acquire(self, acq=L.ACQ_EI, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0):
-        """Returns (argmax index, acquisition value there)."""
+    def acquire(self, acq=L.ACQ_EI, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0, tie_rtol=0.0):
+        """Returns (argmax index, acquisition maximum).  tie_rtol = 0: np.argmax semantics (first occurrence of the exact
+        maximum).  tie_rtol > 0: the lowest index whose value is within tie_rtol * |max| of the maximum, a choice that does not
+        depend on the last bits of values that are mathematically equal (mirror-image candidates on a lattice)."""
         idx, best = C.c_int64(), C.c_double()
         self._check(self._lib.gpbo_acquire(self._h, int(acq), float(kappa), int(incumbent_mode), float(incumbent),
                                            C.byref(idx), C.byref(best)))
+        if tie_rtol > 0.0 and np.isfinite(best.value):
+            first = self.first_at_least(best.value - float(tie_rtol) * abs(best.value))
+            if first >= 0:
+                return first, best.value
         return int(idx.value), best.value
+
+    def first_at_least(self, threshold):
+        """Lowest index whose acquisition value is >= threshold (-1: none)."""
+        idx = C.c_int64()
+        self._check(self._lib.gpbo_first_at_least(self._h, float(threshold), C.byref(idx)))
+        return int(idx.value)
 
     def read(self, mu=True, var=True, acq=False, offset=0, count=None):
         count = self.m - offset if count is None else count
@@ -200,6 +212,17 @@ class GP:
         self._check(self._lib.gpbo_append(self._h, L.dptr(x), float(y_new), C.byref(mm)))
         self._refresh_scalars()
         return mm.value
+
+    def append_acquire(self, x_new, y_new, acq=L.ACQ_EI, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0):
+        """append(x_new, y_new) + acquire(...) over the updated posterior in one call: (max(mu), argmax index, acquisition maximum)."""
+        x = _f64(np.asarray(x_new).reshape(-1), 1)
+        if x.shape[0] != self.d:
+            raise ValueError('x_new has %d entries, the model %d columns' % (x.shape[0], self.d))
+        mm, idx, best = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self._lib.gpbo_append_acquire(self._h, L.dptr(x), float(y_new), int(acq), float(kappa), int(incumbent_mode),
+                                                  float(incumbent), C.byref(mm), C.byref(idx), C.byref(best)))
+        self._refresh_scalars()
+        return mm.value, int(idx.value), best.value
 
     def _refresh_scalars(self):
         t1, nll, ym, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()

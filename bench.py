@@ -289,17 +289,17 @@ def secondary(a):
         m = len(grid)
         sweep_ms, bytes_alg = 0.0, 0.0
         picked = []
+        # an iteration = append the point picked last + sweep + pick the next one (ShardedLoop.step)
+        jj, _, x = loop.propose(bo.ACQ_EI, 0.01)
         for it in range(a.warmup):
-            jj, _, x = loop.propose(bo.ACQ_EI, 0.01)
             picked.append(jj)
-            loop.observe(x, float(f(x)))
+            jj, _, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
         barrier()
         t0 = time.perf_counter()
         for it in range(iters):
-            jj, ei, x = loop.propose(bo.ACQ_EI, 0.01)
             picked.append(jj)
             n_before = gp.n
-            loop.observe(x, float(f(x)))
+            jj, ei, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
             tm = gp.timings()
             sweep_ms += tm['append_sweep_ms']
             bytes_alg += m * (8.0 * n_before + 8 + 32 + 8 * d)     # V read + new V row + (mu, var r/w; sum v^2 r/w) + candidates

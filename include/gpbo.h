@@ -119,6 +119,12 @@ int gpbo_posterior(gpbo_ctx* ctx, double* mu_max_out);
 int gpbo_acquire(gpbo_ctx* ctx, int32_t acq, double kappa, int32_t incumbent_mode,
                  double incumbent, int64_t* argmax_out, double* best_out);
 
+/* Lowest candidate index whose acquisition value (as the last gpbo_acquire left it) is >= threshold; -1 if there is none.
+ * With threshold = best - rtol*|best| this is a tie-tolerant argmax: on an equispaced grid such as the notebooks'
+ * (BayesOpt_v4.ipynb:248) candidates mirrored about a training point have EI equal to the last bit or two, and which
+ * of them np.argmax (:647) returns is round-off of the evaluation order -- the reference's own included. */
+int gpbo_first_at_least(gpbo_ctx* ctx, double threshold, int64_t* index_out);
+
 /* The same acquisition pass for callers that cannot allocate: it has NO counterpart in the reference and exists for
  * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  It needs no context and calls
  * no hipMalloc / hipFree or any allocating routine: the partial results of its two reductions live in a 32 KiB
@@ -149,6 +155,12 @@ int gpbo_predict_ei(gpbo_ctx* ctx, const double* Xs, int64_t m, double kappa,
  * refits from scratch each iteration (BayesOpt_v4.ipynb:642-645); this is the same
  * posterior for frozen theta (GP/BayesOptFcn_v1.m:73-83). */
 int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out);
+
+/* One iteration of the frozen-theta loop in one call and one host synchronisation: gpbo_append(x_new, y_new) followed by
+ * gpbo_acquire over the updated posterior (the body of BayesOpt_v4.ipynb:645-655 for the point picked last time and the
+ * pick of the next one).  Same results, bit for bit, as the two calls; the acquisition array itself is not stored. */
+int gpbo_append_acquire(gpbo_ctx* ctx, const double* x_new, double y_new, int32_t acq, double kappa, int32_t incumbent_mode,
+                        double incumbent, double* mu_max_out, int64_t* argmax_out, double* best_out);
 
 /* Trend-GP ("kriging") flavour.  gpr_poly (Gaussian_Process_Regression.ipynb:197-203): isotropic
  * K = exp(-D^2/(2 theta^2)) WITHOUT jitter, trend basis polymat(deg) (:113-140; d <= 3), GLS

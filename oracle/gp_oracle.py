@@ -174,6 +174,15 @@ def argmax_first(a):
     return int(np.argmax(a))
 
 
+def argmax_tol(a, rtol):
+    """Tie-tolerant argmax: the lowest index whose value is within rtol*|max| of the maximum.  No reference counterpart
+    (np.argmax at BayesOpt_v4.ipynb:647 is rtol = 0); it makes the pick independent of the last bits of values that are
+    mathematically equal, which on the notebook's equispaced grid differ between any two evaluation orders."""
+    a = np.asarray(a, dtype=np.float64)
+    best = np.max(a)
+    return int(np.flatnonzero(a >= best - rtol * abs(best))[0])
+
+
 # --------------------------------------------------------------------------- likelihood
 def mlefcn(xTrain, yTrain, theta, sigmaY, kernel=RBF):
     """-logL of BayesOpt_v4.ipynb:154-165 (Daa argument folded into the kernel build)."""

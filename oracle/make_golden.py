@@ -63,11 +63,128 @@ def save(outdir, name, d):
     print('wrote', name, {k: getattr(v, 'shape', None) for k, v in d.items() if hasattr(v, 'shape') and v.size > 1})
 
 
+def load_cell_defining(path, name, ns):
+    """exec the code cell of notebook `path` that defines function `name` into namespace ns."""
+    nb = json.load(open(path))
+    for c in nb['cells']:
+        src = ''.join(c['source'])
+        if c['cell_type'] == 'code' and ('def ' + name + '(') in src:
+            exec(compile(src, path, 'exec'), ns)
+            return ns
+    raise RuntimeError(name + ' not found in ' + path)
+
+
+def lattice_loop(a, v4):
+    """G8: the body of the 1-D BO loop (BayesOpt_v4.ipynb:642-664) on the notebook's own equispaced grid
+    (x = np.linspace(-5, 5, 400), :248), theta held fixed (the optimiser needs autograd), ten iterations: the sequence of
+    picked indices and max EI, plus the gap between the two largest EI values of every iteration (how close a tie was)."""
+    P = 400
+    x = np.linspace(-5, 5, P)[:, np.newaxis]
+    y = np.exp(-x ** 2) + np.sin(2 * x) * np.cos(10 * x)
+    for tag, s in (('s0', 0.0), ('s1e-2', 1e-2)):
+        ii = [37, 180, 333]
+        xT, yT = x[ii], y[ii]
+        theta = np.array([0.3])
+        jj_hist, ei_hist, gap_hist, mumax_hist, EI, MU, VAR = [], [], [], [], [], [], []
+        for it in range(10):
+            Mu, Cov, _, _, _, _, _, _ = v4['gprfcn'](x, xT, yT, theta, s)
+            ei = v4['expected_improvement'](Mu, Cov, 0.01)
+            jj = int(np.argmax(ei))
+            top2 = np.sort(ei)[-2:]
+            jj_hist.append(jj)
+            ei_hist.append(float(ei[jj]))
+            gap_hist.append(float(top2[1] - top2[0]))
+            mumax_hist.append(float(np.max(Mu)))
+            EI.append(ei.copy())
+            MU.append(np.squeeze(Mu).copy())
+            VAR.append(np.diag(Cov).copy())
+            xT = np.vstack((xT, x[jj, :]))
+            yT = np.vstack((yT, y[jj]))
+        save(a.out, 'g8_lattice_loop_' + tag, dict(x=x, y=y, start=np.array(ii), theta=theta, sigmaY=np.array(s), kappa=np.array(0.01),
+                                                   jj=np.array(jj_hist), ei_max=np.array(ei_hist), top2_gap=np.array(gap_hist),
+                                                   mu_max=np.array(mumax_hist), EI=np.array(EI), Mu=np.array(MU), var=np.array(VAR)))
+
+
+def descent_paths(a, v4, g1_train):
+    """G9: the reference's own conj_gradient_descent (BayesOpt_v4.ipynb:31-87) executed with `grad` (autograd, absent
+    here) replaced by the analytic gradient of the CPU restatement (oracle/gp_oracle.py:mle_grad, itself pinned by
+    central differences of the reference's mlefcn in g6).  g is the reference's mlefcn, exactly as hypopt builds it (:168)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from oracle import gp_oracle as o
+    xT, yT = g1_train
+    sY = 0.05
+    Daa = v4['distmat_v2'](xT, xT)
+    mle = lambda w: float(np.squeeze(v4['mlefcn'](xT, yT, Daa, w, sY)))
+    ns = {'np': np, 'grad': lambda g: (lambda w: o.mle_grad(xT, yT, w, sY))}
+    load_cell_defining(os.path.join(a.ref, 'BayesOpt', 'BayesOpt_v4.ipynb'), 'conj_gradient_descent', ns)
+    cgd = ns['conj_gradient_descent']
+    x0 = 0.08 + 0.5 * o.splitmix64_uniform(33, 4 * 2).reshape(4, 2)
+    out = dict(xTrain=xT, yTrain=yT, sigmaY=np.array(sY), x0=x0)
+    cases = [('component_normal', 0.01, 1, 'component', 'normal', 40), ('component_momentum', 0.01, 0.6, 'component', 'normal', 40),
+             ('full_backtrack', 0.4, 1, 'full', 'backtrack', 6), ('full_diminishing', 0.02, 1, 'full', 'diminishing', 12),
+             ('plain_normal', 1e-5, 1, 'none', 'normal', 25)]
+    for tag, alpha, beta, norm, step, its in cases:
+        W = np.zeros((len(x0), its + 1, 2))
+        Cst = np.zeros((len(x0), its + 1))
+        flags = np.zeros(len(x0), dtype=int)
+        for r in range(len(x0)):
+            wh, ch, fl = cgd(mle, alpha, beta, norm, step, its, x0[r].copy())
+            assert len(wh) == its + 1, (tag, len(wh))
+            W[r] = np.array(wh)
+            Cst[r] = np.array(ch)
+            flags[r] = fl
+        out[tag + '_w'] = W
+        out[tag + '_cost'] = Cst
+        out[tag + '_flag'] = flags
+        out[tag + '_args'] = np.array([alpha, beta, its])
+    save(a.out, 'g9_descent_paths', out)
+
+
+def kriging_more(a, gpr):
+    """More of G7: trend degrees 2 and 3 and three input columns (polymat, Gaussian_Process_Regression.ipynb:113-140), and a
+    nearly singular K on which the reference's LU solves (np.linalg.solve, :201-202) still return numbers."""
+    rng = np.random.default_rng(77)
+
+    def run(name, xT, yT, xS, theta, deg):
+        beta, cov, K, Ks, Kss, FT, FS = gpr['gpr_poly'](xT, yT, xT, theta, 'gaussian', deg)
+        mu = np.zeros(len(xS))
+        mse = np.zeros(len(xS))
+        for i in range(len(xS)):
+            u, v = gpr['y_kriging_v2'](xS[i][None, :], beta, cov, K, FT, xT, yT, theta, deg, 'gaussian')
+            mu[i], mse[i] = np.squeeze(u), np.squeeze(v)
+        save(a.out, name, dict(xT=xT, yT=yT, xS=xS, theta=theta, deg=np.array(deg), beta=np.asarray(beta),
+                               cov=np.array(float(np.squeeze(cov))), mu=mu, mse=mse, condK=np.array(np.linalg.cond(K))))
+
+    s = np.linspace(-5, 5, 1200)
+    Y = np.exp(-s ** 2) + np.cos(2 * s) * np.sin(2 * s)
+    ii = rng.permutation(1200)[:14]
+    run('g7_kriging_1d_deg2', s[ii][:, None], Y[ii], np.linspace(-5, 5, 90)[:, None], np.array([0.8]), 2)
+    g2 = np.linspace(-2, 2, 20)
+    XX = np.array([[u, v] for u in g2 for v in g2])
+    YY = np.sin(XX[:, 0]) * np.cos(XX[:, 1]) + 0.3 * XX[:, 0] + 0.1 * XX[:, 0] * XX[:, 1]
+    ii = rng.permutation(400)[:24]
+    xS2 = rng.uniform(-2, 2, (100, 2))
+    for deg in (2, 3):
+        run('g7_kriging_2d_deg%d' % deg, XX[ii], YY[ii], xS2, np.array([0.9]), deg)
+    X3 = rng.uniform(-1, 1, (40, 3))
+    Y3 = np.sin(2 * X3[:, 0]) + X3[:, 1] * X3[:, 2] + 0.5 * X3[:, 2] ** 2
+    xS3 = rng.uniform(-1, 1, (80, 3))
+    for deg in (0, 1, 2, 3):
+        run('g7_kriging_3d_deg%d' % deg, X3, Y3, xS3, np.array([0.7]), deg)
+    # nearly singular: 60 close points, long length scale -> cond(K) ~ 1e17+; LU with pivoting returns finite numbers
+    xs = np.linspace(0, 1, 60)[:, None]
+    ys = np.sin(3 * xs[:, 0])
+    run('x7_kriging_singular', xs, ys, np.linspace(0, 1, 25)[:, None] + 0.003, np.array([2.0]), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    ap.add_argument('--only', default='', help='comma-separated groups to (re)write, e.g. g8,g9,g7more; default: everything')
     a = ap.parse_args()
+    only = set(filter(None, a.only.split(',')))
     os.makedirs(a.out, exist_ok=True)
     warnings.simplefilter('ignore')
     v4 = load_function_cell(os.path.join(a.ref, 'BayesOpt', 'BayesOpt_v4.ipynb'),
@@ -97,7 +214,16 @@ def main():
     theta = np.array([0.1036165, 0.0995048])          # the author's saved fit, BayesOpt_v4.ipynb:776
     g1 = run_gprfcn(v4, xp, xT, yT, theta, 0.0, 0.01, keep_factor=True)
     g1.update(x_all=x, y_all=y, perm=ind, grid_sx=sx, grid_sy=sy)
-    save(a.out, 'g1_mat_mixture', g1)
+    if not only or 'g1' in only:
+        save(a.out, 'g1_mat_mixture', g1)
+    if not only or 'g8' in only:
+        lattice_loop(a, v4)
+    if not only or 'g9' in only:
+        descent_paths(a, v4, (xT, yT))
+    if not only or 'g7more' in only:
+        kriging_more(a, gpr)
+    if only and not (only & {'g2', 'g3', 'g4', 'g5', 'g6', 'g7'}):
+        return
 
     # ---- G6: likelihood surface on G1's data (analogue of the 500x500 sweep at :727-731), 16x16
     th0 = np.linspace(0.05, 2.0, 16)

@@ -222,3 +222,80 @@ def test_outer_loop_refits_sweeps_and_appends_like_the_1d_notebook_cell():
     out2 = bayes_opt(x, f, x[ii], y[ii], sigmaY=1e-2, ei_tol=10.0, nruns=nruns, max_its=5, starts=starts)
     assert out2['exitflag'] == 1 and len(out2['jj_hist']) == 1 and len(calls) == 1 and out2['xT'].shape == (4, 1)
     assert out2['yT'][3, 0] == y[out2['jj_hist'][0], 0]
+
+
+@pytest.mark.parametrize('name', golden_names('g8'))
+def test_lattice_loop_on_the_notebooks_own_grid(name):
+    """BayesOpt_v4.ipynb:642-664 on x = np.linspace(-5, 5, 400) (:248), theta fixed, ten iterations recorded from the reference.
+    Following the reference's trajectory: the EI array agrees, the device argmax is one of the reference's numerically maximal
+    candidates (mirror images about a training point tie to an ulp; the reference's pick among them is round-off, see the
+    CPU test of the same fixture), and the tie-tolerant pick equals the reference's tie-tolerant pick at every iteration.
+    Free-running with tie_rtol the device loop and the oracle loop pick the same ten points."""
+    from bayesian_optimization_amd import notebook_api as nb
+    g = golden(name)
+    x, y, s, theta = g['x'], g['y'], float(g['sigmaY']), g['theta']
+    ii = list(g['start'])
+    xT, yT = x[ii], y[ii]
+    gp = nb._gp('main')
+    for it in range(len(g['jj'])):
+        Mu, Cov, _, _, _, _, _, _ = nb.gprfcn(x, xT, yT, theta, s)
+        ei = nb.expected_improvement(Mu, Cov, 0.01)
+        ref = g['EI'][it]
+        assert relmax(Mu[:, 0], g['Mu'][it]) <= 1e-9 and relmax(ei, ref) <= 1e-7
+        jj = int(np.argmax(ei))
+        assert ref[jj] >= ref.max() * (1 - 1e-9)
+        jt, best = gp.acquire(0, 0.01, tie_rtol=1e-9)
+        assert jt == o.argmax_tol(ref, 1e-9) and best == ei.max()
+        jr = int(g['jj'][it])
+        xT = np.vstack((xT, x[jr, :])); yT = np.vstack((yT, y[jr]))
+    # free-running, tie-tolerant: device loop == oracle loop
+    xT, yT = x[ii], y[ii]
+    xo, yo = xT.copy(), yT.copy()
+    for it in range(10):
+        gp.fit(xT, yT, theta, s)
+        gp.set_candidates(x)
+        gp.posterior()
+        jj, _ = gp.acquire(0, 0.01, tie_rtol=1e-9)
+        mu_o, var_o, _ = o.gprfcn_diag(x, xo, yo, theta, s)
+        jo = o.argmax_tol(o.expected_improvement(mu_o, var_o, 0.01), 1e-9)
+        assert jj == jo, (it, jj, jo)
+        xT = np.vstack((xT, x[jj, :])); yT = np.vstack((yT, y[jj]))
+        xo = np.vstack((xo, x[jo, :])); yo = np.vstack((yo, y[jo]))
+
+
+def test_first_at_least_and_exact_ties_across_blocks(gp0):
+    import bayesian_optimization_amd as bo
+    m = 700000
+    mu = np.sin(np.arange(m) * 0.001)
+    mu[[650123, 5, 300000]] = 2.0                     # three exact ties, far apart (different reduction workgroups)
+    gp0.set_posterior(mu, np.ones(m))
+    idx, best = gp0.acquire(bo.ACQ_UCB, 0.0)
+    assert (idx, best) == (5, 2.0)
+    assert gp0.first_at_least(2.0) == 5 and gp0.first_at_least(2.0 + 1e-12) == -1
+    assert gp0.first_at_least(1.0 - 1e-7) == int(np.flatnonzero(mu >= 1.0 - 1e-7)[0])
+    mu[5] = 2.0 - 1e-13                               # a near tie: exact argmax moves on, the tolerant one stays
+    gp0.set_posterior(mu, np.ones(m))
+    assert gp0.acquire(bo.ACQ_UCB, 0.0)[0] == 300000
+    assert gp0.acquire(bo.ACQ_UCB, 0.0, tie_rtol=1e-9)[0] == 5
+
+
+from test_oracle_golden import DESCENT_CASES, check_descent_case   # noqa: E402
+
+
+@pytest.mark.parametrize('tag,norm,step', DESCENT_CASES)
+def test_hypopt_walks_the_reference_descent_paths(tag, norm, step):
+    """hypopt on the device-evaluated -logL + gradient against the paths the reference's own conj_gradient_descent walked
+    (BayesOpt_v4.ipynb:31-87, fixture g9): component / full / unnormalised directions, momentum, constant, backtracking and
+    diminishing steps."""
+    from bayesian_optimization_amd import notebook_api as nb
+    check_descent_case(nb.hypopt, golden('g9_descent_paths'), tag, norm, step, 1e-7)
+
+
+def test_singular_kriging_matrix_is_refused_where_the_reference_returns_garbage():
+    """No jitter in this flavour (Gaussian_Process_Regression.ipynb:199-202).  On the fixture's K (cond ~ 1e19) the reference's
+    LU solves return a negative process variance; the library's Cholesky reports the matrix as not positive definite."""
+    from bayesian_optimization_amd import notebook_api as nb
+    g = golden('x7_kriging_singular')
+    assert float(g['cov']) < 0
+    with pytest.raises(np.linalg.LinAlgError):
+        nb.gpr_poly(g['xT'], g['yT'], g['xT'], g['theta'], 'gaussian', int(g['deg']))

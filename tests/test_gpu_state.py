@@ -112,3 +112,34 @@ def test_device_generated_candidates_equal_the_host_stream(gp0):
     b = gp0.read()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert np.array_equal(synth.uniform(7, 50, offset=3), o.splitmix64_uniform(7, 50, offset=3))
+
+
+def test_fused_loop_step_equals_append_then_acquire():
+    """gpbo_append_acquire (one call, one synchronisation, acquisition array not stored) against gpbo_append + gpbo_acquire:
+    the same picks, maxima and posterior, bit for bit, over a run of iterations; odd and even candidate counts (the sweep
+    has a one- and a two-candidates-per-thread form)."""
+    from bayesian_optimization_amd import GP
+    from bayesian_optimization_amd import dist as gdist
+    for m in (30001, 65536):
+        X, y = _data(40, 3, 77)
+        Xs = o.splitmix64_uniform(78, m * 3).reshape(m, 3)
+        f = lambda x: float(np.sin(3 * x.sum()) + 0.2 * x[0])
+        ga, gb = GP(0), GP(0)
+        loops = []
+        for gp in (ga, gb):
+            gp.reserve_appends(12)
+            gp.fit(X, y, np.array([0.4, 0.5, 0.6]), 0.05, variant=bo.VARIANT_SINGLE)
+            loops.append(gdist.ShardedLoop(gp, Xs, 0))
+        ja, _, xa = loops[0].propose(bo.ACQ_EI, 0.01)
+        jb, _, xb = loops[1].propose(bo.ACQ_EI, 0.01)
+        assert ja == jb
+        for it in range(12):
+            loops[0].observe(xa, f(xa))                               # two calls, two round trips
+            ja, ea, xa = loops[0].propose(bo.ACQ_EI, 0.01)
+            jb, eb, xb = loops[1].step(xb, f(xb), bo.ACQ_EI, 0.01)    # one fused call
+            assert (ja, ea) == (jb, eb) and np.array_equal(xa, xb) and loops[0].mu_max == loops[1].mu_max
+        ra, rb = ga.read(), gb.read()
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+        assert ga.n == gb.n == 52 and ga.theta1 == gb.theta1 and ga.nll == gb.nll and ga.y_max == gb.y_max
+        ga.close()
+        gb.close()

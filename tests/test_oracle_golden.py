@@ -131,3 +131,78 @@ def test_oracle_matern_gradient_against_central_differences():
             e[i] = h
             fd = (o.mlefcn(X, y, theta + e, s, kernel=o.MATERN52) - o.mlefcn(X, y, theta - e, s, kernel=o.MATERN52)) / (2 * h)
             assert abs(g[i] - fd) <= 1e-5 * max(1.0, abs(fd)), (i, g[i], fd)
+
+
+@pytest.mark.parametrize('name', golden_names('g8'))
+def test_lattice_loop_against_reference(name):
+    """The 1-D BO loop body on the notebook's own equispaced grid, theta fixed, following the reference's trajectory.
+    Mirror-image candidates about a training point tie to within an ulp or two (top2_gap ~ 1e-17 in the fixture), and
+    which of them np.argmax returns is round-off: at iteration 2 of the sigmaY = 1e-2 case the reference's own arithmetic
+    (LU solves) and this restatement (triangular solves) pick different mirror images.  So: the EI array itself must agree,
+    the pick must be one of the reference's numerically maximal candidates, and the tie-tolerant rule must agree exactly."""
+    g = golden(name)
+    x, y, s, theta = g['x'], g['y'], float(g['sigmaY']), g['theta']
+    ii = list(g['start'])
+    xT, yT = x[ii], y[ii]
+    flips = 0
+    for it in range(len(g['jj'])):
+        mu, var, _ = o.gprfcn_diag(x, xT, yT, theta, s)
+        ei = o.expected_improvement(mu, var, 0.01)
+        ref = g['EI'][it]
+        assert relmax(mu, g['Mu'][it]) <= 1e-9 and relmax(ei, ref) <= 1e-7
+        j = o.argmax_first(ei)
+        assert ref[j] >= ref.max() * (1 - 1e-9)
+        flips += int(j != int(g['jj'][it]))
+        assert o.argmax_tol(ei, 1e-9) == o.argmax_tol(ref, 1e-9)
+        jr = int(g['jj'][it])                      # teacher forcing: continue on the reference's own trajectory
+        xT = np.vstack((xT, x[jr, :]))
+        yT = np.vstack((yT, y[jr]))
+    if name.endswith('s1e-2'):
+        assert flips >= 1                          # the documented coin flip really is in the fixture
+
+
+class _OracleLml:
+    """Stands in for the GPU likelihood sweep so that the optimiser's HOST logic can be checked without a GPU."""
+
+    def lml_batch(self, X, y, thetas, sigmas, kernel=0, grad=False):
+        nll = np.array([o.mlefcn(X, y, t, float(s), kernel) for t, s in zip(thetas, sigmas)])
+        stat = np.zeros(len(nll), dtype=np.int32)
+        if not grad:
+            return nll, stat
+        return nll, np.array([o.mle_grad(X, y, t, float(s), kernel) for t, s in zip(thetas, sigmas)]), stat
+
+
+DESCENT_CASES = [('component_normal', 'component', 'normal'), ('component_momentum', 'component', 'normal'),
+                 ('full_backtrack', 'full', 'backtrack'), ('full_diminishing', 'full', 'diminishing'), ('plain_normal', 'none', 'normal')]
+
+
+def check_descent_case(hypopt, g, tag, norm, step, wtol):
+    alpha, beta, its = g[tag + '_args']
+    W, Cst = g[tag + '_w'], g[tag + '_cost']
+    w_hist, c_hist, flags = hypopt(len(g['x0']), int(its), float(alpha), float(beta), norm, step, g['xTrain'], g['yTrain'], None,
+                                   float(g['sigmaY']), x0=g['x0'])
+    for r in range(len(g['x0'])):
+        assert len(w_hist[r]) == W.shape[1]
+        assert np.max(np.abs(np.array(w_hist[r]) - W[r])) <= wtol, (tag, r)
+        assert np.max(np.abs(np.array(c_hist[r]) - Cst[r]) / np.abs(Cst[r])) <= 1e-7, (tag, r)
+        assert flags[r] == g[tag + '_flag'][r]
+
+
+@pytest.mark.parametrize('tag,norm,step', DESCENT_CASES)
+def test_batched_descent_rule_walks_the_reference_paths(monkeypatch, tag, norm, step):
+    """conj_gradient_descent of the reference (executed by make_golden.py with the analytic gradient in place of autograd's)
+    against the batched restatement of its update rules in bayesian_optimization_amd/hyperopt.py, the likelihood sweep
+    replaced by the CPU restatement: host logic only."""
+    from bayesian_optimization_amd import hyperopt
+    monkeypatch.setitem(hyperopt._ctx, 0, _OracleLml())
+    check_descent_case(hyperopt.hypopt, golden('g9_descent_paths'), tag, norm, step, 1e-9)
+
+
+def test_singular_kriging_fixture_shows_what_the_reference_returns():
+    """K without jitter at cond ~ 1e19: the reference's LU solves return finite numbers, a NEGATIVE process variance among
+    them; the Cholesky-based paths (this restatement's check below, and the GPU library) refuse the matrix instead."""
+    g = golden('x7_kriging_singular')
+    assert float(g['condK']) > 1e16 and float(g['cov']) < 0 and np.all(np.isfinite(g['mu']))
+    K = o.kernel_matrix(g['xT'], g['xT'], np.full(1, float(g['theta'][0])))
+    with pytest.raises(np.linalg.LinAlgError):
+        np.linalg.cholesky(K)
