@@ -14,7 +14,7 @@ constexpr int PB = 128;    // Cholesky panel / diagonal block
 
 // params block on the device (doubles)
 enum { P_THETA1 = 0, P_CB = 1, P_C0 = 2, P_C1 = 3, P_NLL = 4, P_YA = 5, P_SUMLOG = 6, P_YMAX = 7, P_INVTHETA = 8,
-       P_BETA = 40, P_NBETA = 52, P_DEG = 53, P_CLAMP = 54 };
+       P_BETA = 40, P_NBETA = 52, P_DEG = 53, P_CLAMP = 54, P_REFINE = 55, P_COND = 56 };
 constexpr int PARAMS_DOUBLES = 64;
 
 // A batched context holds S problems of the same shape side by side ("slots": every buffer is S times as long) and
@@ -623,7 +623,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
 // Forward step p: z_p = inv(L_pp) w_p ; w_ib -= L[ib,p] z_p for ib > p.   grid = nb - p.
 __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, long ld,
                                                        const double* __restrict__ Dinv, double* __restrict__ w,
-                                                       double* __restrict__ z, int p, BatchStride bs) {
+                                                       double* __restrict__ z, int p, BatchStride bs,
+                                                       const double* __restrict__ gate) {
+    if (gate && gate[blockIdx.z * bs.par] == 0.0) return;      // a refinement solve the model does not need
     __shared__ double yp[PB];
     L += blockIdx.z * bs.mat;
     Dinv += blockIdx.z * bs.dinv;
@@ -674,7 +676,9 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict_
 // Backward step p (L^T x = z): x_p = inv(L_pp)^T z_p ; z_jb -= L[p,jb]^T x_p for jb < p.  grid = p + 1.
 __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, long ld,
                                                        const double* __restrict__ Dinv, double* __restrict__ z,
-                                                       double* __restrict__ x, int p, BatchStride bs) {
+                                                       double* __restrict__ x, int p, BatchStride bs,
+                                                       const double* __restrict__ gate) {
+    if (gate && gate[blockIdx.z * bs.par] == 0.0) return;
     __shared__ double zp[PB];
     L += blockIdx.z * bs.mat;
     Dinv += blockIdx.z * bs.dinv;
@@ -708,6 +712,105 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
     red[tid] = s;
     __syncthreads();
     if (tid < PB) z[jb * PB + tid] -= red[tid] + red[tid + 128];
+}
+
+// One step of iterative refinement of alpha1 = (K0 + eps I)^-1 y against the covariance matrix itself (rebuilt entry by
+// entry, the factor is not used for the residual): r = y - (K0 + eps I) alpha1, delta = L^-T L^-1 r, alpha1 += delta.
+// It removes what the blocked substitution (explicitly inverted 128x128 diagonal blocks) and the factor's backward error
+// add on top of a LAPACK-style solve when K0 + eps I is badly conditioned (sigmaY = 0: eps = 1e-15 n): theta1 = y.alpha1/n
+// is then off by ~cond * 1e-17 (1e-6 at cond 4e11), and with it the variance.  Gated on the device: k_refine_flag sets
+// params[P_REFINE] from (max diag L / min diag L)^2, and every kernel of the step returns at once when it is 0.
+constexpr double REFINE_COND = 1e7;
+__global__ __launch_bounds__(256) void k_refine_flag(const double* __restrict__ L, long ld, int n, double* __restrict__ params,
+                                                     BatchStride bs) {
+    __shared__ double lo[256], hi[256];
+    L += blockIdx.z * bs.mat;
+    params += blockIdx.z * bs.par;
+    const int tid = threadIdx.x;
+    double a = INFINITY, b = -INFINITY;
+    for (int i = tid; i < n; i += 256) {
+        const double v = L[(long)i * ld + i];
+        a = fmin(a, v);
+        b = fmax(b, v);
+    }
+    lo[tid] = a;
+    hi[tid] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            lo[tid] = fmin(lo[tid], lo[tid + o]);
+            hi[tid] = fmax(hi[tid], hi[tid + o]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double c = (hi[0] / lo[0]) * (hi[0] / lo[0]);
+        params[P_COND] = c;
+        params[P_REFINE] = (c > REFINE_COND) ? 1.0 : 0.0;      // NaN compares false: a failed factorisation is not refined
+    }
+}
+
+// r_i = y_i - sum_j k(x_i, x_j) a_j - eps a_i for REF_ROWS rows per workgroup; the row's products are summed over
+// j = tid, tid + 256, ... and then over the 256 threads in a fixed tree (deterministic).
+constexpr int REF_ROWS = 8;
+__global__ __launch_bounds__(256) void k_refine_residual(const double* __restrict__ Xts, int n, int n_pad, int d,
+                                                         const double* __restrict__ y, const double* __restrict__ a,
+                                                         double eps_val, const double* __restrict__ eps_ptr, int kernel,
+                                                         const double* __restrict__ params, double* __restrict__ r, BatchStride bs) {
+    if (params[blockIdx.z * bs.par + P_REFINE] == 0.0) return;
+    Xts += blockIdx.z * bs.xts;
+    y += blockIdx.z * bs.vec;
+    a += blockIdx.z * bs.vec;
+    r += blockIdx.z * bs.vec;
+    const double eps = eps_ptr ? eps_ptr[blockIdx.z * bs.slot] : eps_val;
+    __shared__ double red[REF_ROWS][256];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * REF_ROWS;
+    double acc[REF_ROWS];
+#pragma unroll
+    for (int q = 0; q < REF_ROWS; ++q) acc[q] = 0.0;
+    for (int j = tid; j < n; j += 256) {
+        const double aj = a[j];
+        double D[REF_ROWS];
+#pragma unroll
+        for (int q = 0; q < REF_ROWS; ++q) D[q] = 0.0;
+        for (int t = 0; t < d; ++t) {
+            const double xj = Xts[(long)t * n_pad + j];
+            const double* xi = Xts + (long)t * n_pad + i0;
+#pragma unroll
+            for (int q = 0; q < REF_ROWS; ++q) {
+                const double df = xi[q] - xj;
+                D[q] += df * df;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < REF_ROWS; ++q) {
+            const int i = i0 + q;
+            const double kij = (i == j) ? 1.0 + eps : kern_eval(D[q], kernel);
+            acc[q] = fma(kij, aj, acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < REF_ROWS; ++q) red[q][tid] = acc[q];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+#pragma unroll
+            for (int q = 0; q < REF_ROWS; ++q) red[q][tid] += red[q][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid < REF_ROWS) {
+        const int i = i0 + tid;
+        r[i] = (i < n) ? y[i] - red[tid][0] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_refine_add(double* __restrict__ a, const double* __restrict__ delta, int n_pad,
+                                                    const double* __restrict__ params, BatchStride bs) {
+    if (params[blockIdx.z * bs.par + P_REFINE] == 0.0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_pad) a[blockIdx.z * bs.vec + i] += delta[blockIdx.z * bs.vec + i];
 }
 
 // theta1 = y.alpha1/n, sum log diag L, -logL, scale factors and the alpha used for the mean.

@@ -16,7 +16,7 @@ import sys
 import time
 
 import numpy as np
-from scipy.linalg import lapack, solve_triangular
+from scipy.linalg import solve_triangular
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -45,30 +45,52 @@ def candidates(cfg, rows):
     return out
 
 
-def lean_fit_v4(X, y, theta, sigmaY, kernel, blk=2048):
-    """o.fit(variant=V4) with two n x n matrices: same kernel functions, same jitter rule, dpotrf in place."""
+def chol_lower(A, pb):
+    """Lower Cholesky factor of A, overwriting its lower triangle (the strict upper triangle keeps stale values that no
+    triangular solve reads): right-looking over panels of pb columns, np.linalg.cholesky on the diagonal block, a
+    triangular solve for the panel, GEMMs for the trailing update.  Stands in for one np.linalg.cholesky call because
+    OpenBLAS 0.3.29 (numpy's and scipy's builds alike) segfaults inside dpotrf at n = 32768 in this container."""
+    n = A.shape[0]
+    for p in range(0, n, pb):
+        e = min(n, p + pb)
+        Lpp = np.linalg.cholesky(A[p:e, p:e])
+        A[p:e, p:e] = Lpp
+        if e < n:
+            A[e:, p:e] = solve_triangular(Lpp, A[e:, p:e].T, lower=True).T
+            for q in range(e, n, 4096):          # trailing update in row slabs (bounded temporaries), lower part only
+                f = min(n, q + 4096)
+                A[q:f, e:f] -= A[q:f, p:e] @ A[e:f, p:e].T
+    return A
+
+
+def lean_fit_v4(X, y, theta, sigmaY, kernel, blk=2048, pb=4096):
+    """o.fit(variant=V4) with fewer n x n temporaries: the same kernel functions (block by block), the same jitter rule, the
+    same np.linalg.cholesky / solve_triangular calls.  (scipy's own LAPACK segfaults in dpotrf at n = 32768; numpy's does not.)"""
     n = X.shape[0]
     eps = o.jitter(n, sigmaY)
-    A = np.empty((n, n), order='F')
+    A = np.empty((n, n))
     for lo in range(0, n, blk):
         hi = min(n, lo + blk)
-        A[:, lo:hi] = o.kernel_matrix(X, X[lo:hi], theta, kernel)
-    B = A.copy(order='F')
-    B[np.diag_indices(n)] += eps
-    B, info = lapack.dpotrf(B, lower=1, overwrite_a=1, clean=1)
-    if info != 0:
-        raise np.linalg.LinAlgError('first factor: dpotrf info %d' % info)
-    a1 = solve_triangular(B, y, lower=True)
-    a1 = solve_triangular(B, a1, lower=True, trans='T')
+        A[lo:hi, :] = o.kernel_matrix(X[lo:hi], X, theta, kernel)
+    A[np.diag_indices(n)] += eps
+    K0 = None
+    if n > 16384:
+        K0 = A.copy()
+        L1 = chol_lower(A, pb)                                    # K0 + eps I, in place
+    else:
+        L1 = np.linalg.cholesky(A)
+    a1 = solve_triangular(L1, y, lower=True)
+    a1 = solve_triangular(L1, a1, lower=True, trans='T')
     theta1 = float(y @ a1) / n
-    nll = n / 2 * (math.log(2 * math.pi) + 1) + n / 2 * math.log(theta1) + float(np.sum(np.log(np.diag(B))))
-    del B
+    nll = n / 2 * (math.log(2 * math.pi) + 1) + n / 2 * math.log(theta1) + float(np.sum(np.log(np.diag(L1))))
+    del L1
+    if K0 is not None:
+        A = K0
+    A[np.diag_indices(n)] = 1.0                                   # back to K0: k(x, x) = 1 exactly for both kernels
     A *= theta1
     A[np.diag_indices(n)] += eps
-    A, info = lapack.dpotrf(A, lower=1, overwrite_a=1, clean=1)
-    if info != 0:
-        raise np.linalg.LinAlgError('second factor: dpotrf info %d' % info)
-    return dict(X=X, y=y, theta=theta, sigmaY=float(sigmaY), kernel=kernel, variant=o.VARIANT_V4, n=n, L2=A, alpha1=a1,
+    L2 = chol_lower(A, pb) if n > 16384 else np.linalg.cholesky(A)   # theta1 K0 + eps I
+    return dict(X=X, y=y, theta=theta, sigmaY=float(sigmaY), kernel=kernel, variant=o.VARIANT_V4, n=n, L2=L2, alpha1=a1,
                 alpha=a1 / theta1, theta1=theta1, nll=nll, eps=eps)
 
 
@@ -82,7 +104,10 @@ def self_check():
     mb, vb = o.predict(b, Xs)
     assert abs(a['theta1'] - b['theta1']) <= 1e-13 * b['theta1'] and abs(a['nll'] - b['nll']) <= 1e-12 * abs(b['nll'])
     assert np.max(np.abs(ma - mb)) <= 1e-12 * np.max(np.abs(mb)) and np.max(np.abs(va - vb)) <= 1e-12 * np.max(np.abs(vb))
-    print('lean fit == oracle.fit at n=700')
+    K = o.kernel_matrix(X, X, th, cfg['kernel']) + 0.01 * np.eye(700)
+    Lb = np.tril(chol_lower(K.copy(), 256))
+    assert np.max(np.abs(Lb - np.linalg.cholesky(K))) <= 1e-13
+    print('lean fit == oracle.fit at n=700; blocked factor == np.linalg.cholesky')
 
 
 def do_fit():

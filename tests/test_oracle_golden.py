@@ -206,3 +206,18 @@ def test_singular_kriging_fixture_shows_what_the_reference_returns():
     K = o.kernel_matrix(g['xT'], g['xT'], np.full(1, float(g['theta'][0])))
     with pytest.raises(np.linalg.LinAlgError):
         np.linalg.cholesky(K)
+
+
+def test_reference_values_of_the_ill_conditioned_case_are_defined_to_about_5e_7():
+    """Basis of the loose bounds on conftest.ILL_CONDITIONED: CPU variants of the SAME algorithm (Cholesky with other panel
+    widths, K perturbed by one ulp per entry) move theta1 by more than 1e-7 and alpha by more than 3e-7 each, yet never by
+    more than the GPU bounds allow."""
+    import sys
+    from conftest import ILL_TOL_MU, ILL_TOL_VAR, ROOT
+    sys.path.insert(0, ROOT + '/scripts')
+    from illcond_noise_floor import noise_floor
+    r = noise_floor(extended=False)
+    moves = list(r['panel'].values()) + r['ulp']
+    assert r['cond'] > 1e11
+    assert min(t for t, _ in moves) > 1e-7 and min(a for _, a in moves) > 3e-7
+    assert max(t for t, _ in moves) < ILL_TOL_VAR and max(a for _, a in moves) < ILL_TOL_MU
