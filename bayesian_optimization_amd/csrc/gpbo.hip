@@ -93,6 +93,8 @@ struct gpbo_ctx {
     int64_t m = 0, m_cap = 0, xs_cap = 0;   // m_cap: outputs (doubles per array); xs_cap: doubles in Xs
     int64_t xs_rows = 0;                    // candidate rows resident in Xs (m may differ after gpbo_set_posterior)
     double *mu = nullptr, *var = nullptr, *acq = nullptr;
+    double* res_host = nullptr;                  // pinned, device-mapped result block of a loop step (STEP_RES_DOUBLES)
+    double* res_dev = nullptr;                   // the device's address of res_host
     double *acq_pv = nullptr, *bmax = nullptr;   // per-workgroup partials: fused acquisition/argmax, max(mu) of the append sweep
     long* acq_pi = nullptr;
     bool have_posterior = false;
@@ -636,11 +638,10 @@ int append_check(gpbo_ctx* ctx, const double* x_new) {
 int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new) {
     const int n = (int)ctx->n;
     const long ld = ctx->n_pad;
-    ctx->h_xnew.assign(MAX_D, 0.0);
-    for (int t = 0; t < ctx->d; ++t) ctx->h_xnew[t] = x_new[t] / ctx->theta[t];
-    HIPCHK(hipMemcpyAsync(ctx->xnew_dev, ctx->h_xnew.data(), MAX_D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+    PointArg pa;
+    for (int t = 0; t < MAX_D; ++t) pa.x[t] = (t < ctx->d) ? x_new[t] / ctx->theta[t] : 0.0;
     Scope tot(ctx, T_TOTAL);
+    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(64), 0, ctx->stream, pa, ctx->xnew_dev, ctx->info_dev);
     hipLaunchKernelGGL(k_append_kvec, dim3((unsigned)((ctx->n_pad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xts, n,
                        (int)ctx->n_pad, ctx->d, (const double*)ctx->xnew_dev, ctx->kvec, ctx->kernel);
     hipLaunchKernelGGL(k_append_lvec, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const double*)ctx->bufW, ld, n,
@@ -665,18 +666,23 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new) {
             default: launch_sweep_t<0>(ctx); break;
         }
     }
-    // stage 2 of max(mu): one workgroup over the sweep's per-workgroup maxima
+    // stages 2 and 3 of max(mu) over the sweep's per-workgroup maxima; the last one also fills the incumbent slot
+    // (used when the acquisition that follows takes max(mu) as its incumbent)
     const long sweep_blocks = (ctx->m % 2 == 0) ? (ctx->m / 2 + 255) / 256 : (ctx->m + 255) / 256;
-    hipLaunchKernelGGL(k_max_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bmax, sweep_blocks, ctx->inc_dev + 1);
+    const int b2 = (int)std::min<long>(256, (sweep_blocks + 255) / 256);
+    hipLaunchKernelGGL(k_max_stage, dim3(b2), dim3(256), 0, ctx->stream, (const double*)ctx->bmax, sweep_blocks, ctx->red_v, (double*)nullptr);
+    hipLaunchKernelGGL(k_max_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->red_v, (long)b2, ctx->inc_dev + 1, ctx->inc_dev);
     HIPCHK(hipGetLastError());
     return GPBO_OK;
 }
 
 // acquisition + argmax stage 1 fused, stage 2; results stay in red_v2 / red_i2.  store: keep the acquisition array.
-int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumbent, bool store) {
+int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumbent, bool store, bool inc_ready = false) {
     if (acq < 0 || acq > 2) BADARG("acquire: unknown acquisition");
     Scope s(ctx, T_ACQ);
-    if (mode == GPBO_INCUMBENT_MAX_MU)
+    if (mode == GPBO_INCUMBENT_MAX_MU && inc_ready) {
+        // the max stage that just ran has written max(mu) into the incumbent slot as well
+    } else if (mode == GPBO_INCUMBENT_MAX_MU)
         hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, (const double*)(ctx->inc_dev + 1));
     else if (mode == GPBO_INCUMBENT_MAX_Y)
         hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, (const double*)(ctx->params + P_YMAX));
@@ -705,16 +711,18 @@ struct StepResult {      // what one synchronisation brings back
 };
 
 int step_fetch(gpbo_ctx* ctx, StepResult* r, bool want_append, bool want_acquire) {
-    if (want_append) {
-        HIPCHK(hipMemcpyAsync(r->par, ctx->params, sizeof(r->par), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&r->info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&r->mu_max, ctx->inc_dev + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    if (want_acquire) {
-        HIPCHK(hipMemcpyAsync(&r->best, ctx->red_v2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&r->best_i, ctx->red_i2, sizeof(long), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    (void)want_append;
+    (void)want_acquire;
+    // one small kernel stores everything into the pinned result block; the synchronisation is the whole transfer
+    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->params, (const int*)ctx->info_dev,
+                       (const double*)(ctx->inc_dev + 1), (const double*)ctx->red_v2, (const long*)ctx->red_i2, ctx->res_dev);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(r->par, ctx->res_host, sizeof(r->par));
+    r->info = (int)ctx->res_host[8];
+    r->mu_max = ctx->res_host[9];
+    r->best = ctx->res_host[10];
+    memcpy(&r->best_i, ctx->res_host + 11, sizeof(long));
     return GPBO_OK;
 }
 
@@ -773,7 +781,7 @@ int append_acquire_impl(gpbo_ctx* ctx, const double* x_new, double y_new, int ac
     if (mode < 0 || mode > 2) BADARG("append_acquire: unknown incumbent mode");
     timing_begin(ctx);
     CHK(append_enqueue(ctx, x_new, y_new));
-    CHK(acquire_enqueue(ctx, acq, kappa, mode, incumbent, false));
+    CHK(acquire_enqueue(ctx, acq, kappa, mode, incumbent, false, true));
     StepResult r{};
     CHK(step_fetch(ctx, &r, true, true));
     CHK(append_finish(ctx, r, mu_max_out));
@@ -844,7 +852,9 @@ int gpbo_create(int device, gpbo_ctx** out) {
               hipMalloc((void**)&ctx->red_i2, 8 * sizeof(long)) == hipSuccess &&
               hipMalloc((void**)&ctx->inc_dev, 8 * sizeof(double)) == hipSuccess &&
               hipMalloc((void**)&ctx->scal, 8 * sizeof(double)) == hipSuccess &&
-              hipMalloc((void**)&ctx->xnew_dev, MAX_D * sizeof(double)) == hipSuccess;
+              hipMalloc((void**)&ctx->xnew_dev, MAX_D * sizeof(double)) == hipSuccess &&
+              hipHostMalloc((void**)&ctx->res_host, STEP_RES_DOUBLES * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void**)&ctx->res_dev, ctx->res_host, 0) == hipSuccess;
     if (!ok) {
         gpbo_destroy(ctx);
         return GPBO_ERR_HIP;
@@ -868,6 +878,7 @@ void gpbo_destroy(gpbo_ctx* ctx) {
                   ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres,     ctx->acq_pv,  ctx->acq_pi, ctx->bmax};
     for (void* p : ps)
         if (p) hipFree(p);
+    if (ctx->res_host) hipHostFree(ctx->res_host);
     for (auto e : ctx->pool) hipEventDestroy(e);
     if (ctx->sm_buf) hipFree(ctx->sm_buf);
     if (ctx->lane_graph) hipGraphExecDestroy(ctx->lane_graph);

@@ -1023,7 +1023,9 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
 
 // ---------------------------------------------------------------------------------------
 // Reductions: max and (value, first index) argmax, two stages, deterministic.
-__global__ __launch_bounds__(256) void k_max_stage(const double* __restrict__ a, long m, double* __restrict__ out) {
+// out2 (optional, single-workgroup launches): a second destination for the result (the incumbent slot of the acquisition)
+__global__ __launch_bounds__(256) void k_max_stage(const double* __restrict__ a, long m, double* __restrict__ out,
+                                                   double* __restrict__ out2 = nullptr) {
     __shared__ double r[256];
     const int tid = threadIdx.x;
     double v = -INFINITY;
@@ -1034,7 +1036,35 @@ __global__ __launch_bounds__(256) void k_max_stage(const double* __restrict__ a,
         if (tid < o) r[tid] = fmax(r[tid], r[tid + o]);
         __syncthreads();
     }
-    if (tid == 0) out[blockIdx.x] = r[0];
+    if (tid == 0) {
+        out[blockIdx.x] = r[0];
+        if (out2) out2[blockIdx.x] = r[0];
+    }
+}
+
+// Start of a loop step: the new scaled point goes to device memory and the status word is cleared, in one launch
+// (instead of a host-to-device copy and a fill, each a separate trip through the runtime).
+struct PointArg {
+    double x[MAX_D];
+};
+__global__ void k_step_begin(PointArg p, double* __restrict__ xnew, int* __restrict__ info) {
+    const int t = threadIdx.x;
+    if (t < MAX_D) xnew[t] = p.x[t];
+    if (t == 0) *info = 0;
+}
+
+// End of a loop step: everything the host reads back, gathered into one block (pinned host memory mapped into the
+// device's address space: the kernel's stores are the transfer).  res: [0..7] params head, [8] info, [9] max(mu),
+// [10] best acquisition value, [11] its index (bit pattern of an int64).
+constexpr int STEP_RES_DOUBLES = 16;
+__global__ void k_step_end(const double* __restrict__ params, const int* __restrict__ info, const double* __restrict__ mu_max,
+                           const double* __restrict__ best_v, const long* __restrict__ best_i, double* __restrict__ res) {
+    const int t = threadIdx.x;
+    if (t < 8) res[t] = params[t];
+    if (t == 8) res[8] = (double)*info;
+    if (t == 9) res[9] = *mu_max;
+    if (t == 10) res[10] = *best_v;
+    if (t == 11) reinterpret_cast<long*>(res)[11] = *best_i;
 }
 
 __device__ __forceinline__ bool better(double v, long i, double bv, long bi) {
