@@ -287,9 +287,14 @@ int chol_group(int nb) {
 void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, int p0, int g) {
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
+    static const bool potrf_valu = getenv("GPBO_POTRF_VALU") && atoi(getenv("GPBO_POTRF_VALU")) != 0;
+    static const int potrf_threads = getenv("GPBO_POTRF_THREADS") ? atoi(getenv("GPBO_POTRF_THREADS")) : POTRF_MFMA_THREADS;
     for (int q = p0; q < p0 + g; ++q) {
         const unsigned S = (unsigned)ctx->batch;
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs);
+        if (potrf_valu)
+            hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs);
+        else
+            hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1, 1, S), dim3(potrf_threads), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs);
         if (q + 1 < nb)
             hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1, 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
         const int rest = p0 + g - 1 - q;      // the group's block columns right of q take panel q at once (K = 128):

@@ -436,13 +436,196 @@ __device__ __forceinline__ void trinv128_lds(double* __restrict__ M, double* __r
     trinv_level<64, 4, 4>(M, T);
 }
 
+// ---------------------------------------------------------------------------------------
+// MFMA form of the diagonal block (potrf128_mfma + trinv128_mfma): the block lives packed in LDS as before, but
+//   * a 16x16 diagonal tile is factored AND inverted by one wave entirely in registers: lane i < 16 holds row i, the pivot
+//     and the multipliers of other rows arrive through v_readlane (uniform, no LDS round trip, no barrier inside);
+//     its inverse is built column-wise (lane c holds column c) from the same registers;
+//   * the rows below a tile are multiplied by that inverse, and the trailing triangle is updated, on v_mfma_f64_16x16x4;
+//   * the inverse of the whole block is assembled from the eight tile inverses by recursive doubling on MFMA.
+// Fragment conventions of v_mfma_f64_16x16x4 (as in gemm_f64.hpp): operand A: lane l holds A[l & 15][l >> 4],
+// operand B: B[l >> 4][l & 15], result: element r of lane l is D[(l >> 4) + 4 r][l & 15].
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int LEAF_P = 17;                        // pitch of a 16x16 tile inverse in LDS
+constexpr int LEAF_DOUBLES = 16 * LEAF_P;
+
+// Wave-level: Cholesky factor of the 16x16 tile at (c0, c0) of the packed block M, written back in place, and its
+// inverse into Wi[i * LEAF_P + c].  Returns the first failing column (pivot <= 0 or NaN) or -1.  Lanes >= 16 idle along.
+__device__ __forceinline__ int leaf_potrf_inv(double* __restrict__ M, int c0, double* __restrict__ Wi) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15;
+    double v[16], rdv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = (c <= i) ? M[tri_off(c0 + i) + c0 + c] : 0.0;
+    int fail = -1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double piv = readlane_f64(v[j], j);
+        if (!(piv > 0.0) && fail < 0) fail = c0 + j;
+        // 1/sqrt from the hardware estimate and two Newton steps, sqrt as piv * (1/sqrt) with one correction
+        double rd = __builtin_amdgcn_rsq(piv);
+        rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
+        rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
+        double d = piv * rd;
+        d = fma(0.5 * rd, fma(-d, d, piv), d);
+        rdv[j] = rd;
+        const double lij = (i > j) ? v[j] * rd : 0.0;
+        v[j] = (i == j) ? d : lij;                 // rows above the diagonal hold zero in this column
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+            const double lcj = readlane_f64(v[j], c);          // L[c][j], uniform
+            v[c] = fma(-lij, lcj, v[c]);           // entries right of a row's diagonal pick up values nobody reads
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c <= i) M[tri_off(c0 + i) + c0 + c] = v[c];
+    }
+    // inverse, column-wise: lane c solves L w = e_c by forward substitution; L[r][k] = row r's register k, uniform
+    double w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        double acc = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) acc = fma(-readlane_f64(v[k], r), w[k], acc);
+        w[r] = acc * rdv[r];
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Wi[r * LEAF_P + i] = w[r];
+    }
+    return fail;
+}
+
+// Factor of the packed 128x128 block M in place; Wi8: [8][LEAF_DOUBLES] receives the inverses of the eight diagonal tiles.
+// All 256 threads must call it; ends on a barrier.
+__device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __restrict__ Wi8, int* __restrict__ failp) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int jb = 0; jb < 8; ++jb) {
+        const int c0 = 16 * jb;
+        double* Wi = Wi8 + jb * LEAF_DOUBLES;
+        GPBO_STAMP(0, 0);
+        if (w == 0) {
+            const int fail = leaf_potrf_inv(M, c0, Wi);
+            if (lane == 0 && fail >= 0 && *failp < 0) *failp = fail;
+        }
+        __syncthreads();
+        GPBO_STAMP(1, 1);
+        const int nt = 7 - jb;                       // 16-row tiles below the diagonal tile
+        // rows below: X = A[rows, c0:c0+16] * inv(L11)^T, one tile per wave and turn
+        for (int t = w; t < nt; t += nw) {
+            const int r0 = c0 + 16 + 16 * t;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double a = M[tri_off(r0 + li) + c0 + 4 * q + lk];
+                const double b = Wi[li * LEAF_P + 4 * q + lk];          // B[k][j] = inv(L11)[j][k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[tri_off(r0 + lk + 4 * r) + c0 + li] = acc[r];
+        }
+        __syncthreads();
+        GPBO_STAMP(2, 1);
+        // trailing triangle: A[I, J] -= X_I X_J^T over the tile pairs I >= J
+        const int npair = nt * (nt + 1) / 2;
+        for (int pr = w; pr < npair; pr += nw) {
+            int ti, tj;
+            tri_decode(pr, ti, tj);
+            const int rI = c0 + 16 + 16 * ti, rJ = c0 + 16 + 16 * tj;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double a = M[tri_off(rI + li) + c0 + 4 * q + lk];
+                const double b = M[tri_off(rJ + li) + c0 + 4 * q + lk];  // B[k][j] = X_J[j][k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rI + lk + 4 * r, col = rJ + li;
+                if (col <= row) M[tri_off(row) + col] -= acc[r];
+            }
+        }
+        __syncthreads();
+        GPBO_STAMP(3, 1);
+    }
+}
+
+// One level of the block inverse on MFMA.  Before: the diagonal blocks of size S hold their inverses, the blocks below
+// them still hold L.  Pair p joins A = [2pS, 2pS+S) and B = A + S:  W[B,A] = -W[B,B] (L[B,A] W[A,A]).
+template <int S>
+__device__ __forceinline__ void trinv_level_mfma(double* __restrict__ M, double* __restrict__ T) {
+    constexpr int P = PB / (2 * S), NT = S / 16, TP = S + 1;
+    constexpr int TILES = P * NT * NT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = w; t < TILES; t += nw) {            // T = L[B,A] W[A,A]; W[A,A] lower: k-tiles kt >= jt
+        const int p = t / (NT * NT), it = (t / NT) % NT, jt = t % NT;
+        const int a0 = 2 * p * S, b0 = a0 + S;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kt = jt; kt < NT; ++kt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 16 * kt + 4 * q + lk, j = 16 * jt + li;
+                const double a = M[tri_off(b0 + 16 * it + li) + a0 + k];
+                const double bv = M[tri_off(a0 + k) + a0 + (j <= k ? j : k)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (j <= k) ? bv : 0.0, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[p * S * TP + (16 * it + lk + 4 * r) * TP + 16 * jt + li] = acc[r];
+    }
+    __syncthreads();
+    for (int t = w; t < TILES; t += nw) {            // W[B,A] = -W[B,B] T; W[B,B] lower: k-tiles kt <= it
+        const int p = t / (NT * NT), it = (t / NT) % NT, jt = t % NT;
+        const int a0 = 2 * p * S, b0 = a0 + S;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kt = 0; kt <= it; ++kt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 16 * kt + 4 * q + lk, i = 16 * it + li;
+                const double av = M[tri_off(b0 + i) + b0 + (k <= i ? k : i)];
+                const double b = T[p * S * TP + k * TP + 16 * jt + li];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((k <= i) ? av : 0.0, b, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[tri_off(b0 + 16 * it + lk + 4 * r) + a0 + 16 * jt + li] = -acc[r];
+    }
+    __syncthreads();
+}
+
+// Inverse of the packed lower-triangular block M in place, given the inverses of its eight diagonal tiles.
+// T: 64 * 65 doubles.  All 256 threads; ends on a barrier.
+__device__ __forceinline__ void trinv128_mfma(double* __restrict__ M, const double* __restrict__ Wi8, double* __restrict__ T) {
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 8 * 256; idx += blockDim.x) {      // tile inverses into the diagonal tiles
+        const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
+        if (c <= r) M[tri_off(16 * b + r) + 16 * b + c] = Wi8[b * LEAF_DOUBLES + r * LEAF_P + c];
+    }
+    __syncthreads();
+    trinv_level_mfma<16>(M, T);
+    trinv_level_mfma<32>(M, T);
+    trinv_level_mfma<64>(M, T);
+}
+
+template <bool MFMA>
 __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
                                                 int* __restrict__ info, double* __restrict__ S) {
     __shared__ int fail_s;
     const int tid = threadIdx.x;
     double* blk = A + (long)p * PB * ld + (long)p * PB;
+    double* Tbuf = S + POTRF_LDS_PACKED;
+    double* Wi8 = Tbuf + TRINV_T_DOUBLES;          // only the MFMA form has (and uses) this space
     if (tid == 0) fail_s = -1;
-    for (int idx = tid; idx < PB * PB / 2; idx += POTRF_THREADS) {      // lower triangle -> packed LDS
+    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {      // lower triangle -> packed LDS
         const int r = idx >> 6, c = (idx & 63) * 2;
         if (c <= r) {
             const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)r * ld + c);
@@ -452,10 +635,11 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     }
     __syncthreads();
     GPBO_STAMP(4, 0);
-    potrf128_lds(S, &fail_s);
+    if (MFMA) potrf128_mfma(S, Wi8, &fail_s);
+    else potrf128_lds(S, &fail_s);
     GPBO_STAMP(5, 0);
     if (tid == 0 && fail_s >= 0) atomicCAS(info, 0, p * PB + fail_s + 1);
-    for (int idx = tid; idx < PB * PB / 2; idx += POTRF_THREADS) {      // L -> global, zeros above the diagonal
+    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {      // L -> global, zeros above the diagonal
         const int r = idx >> 6, c = (idx & 63) * 2;
         f64x2 v;
         v.x = (c <= r) ? S[tri_off(r) + c] : 0.0;
@@ -464,10 +648,11 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     }
     __syncthreads();
     GPBO_STAMP(6, 1);
-    trinv128_lds(S, S + POTRF_LDS_PACKED);
+    if (MFMA) trinv128_mfma(S, Wi8, Tbuf);
+    else trinv128_lds(S, Tbuf);
     GPBO_STAMP(7, 1);
     double* dinv = Dinv + (long)p * PB * PB;
-    for (int idx = tid; idx < PB * PB / 2; idx += POTRF_THREADS) {
+    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
         const int r = idx >> 6, c = (idx & 63) * 2;
         f64x2 v;
         v.x = (c <= r) ? S[tri_off(r) + c] : 0.0;
@@ -476,12 +661,15 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     }
 }
 
-// The LDS request (packed L + the product buffer of the inverse, 99 KB) keeps every tile-engine workgroup (72 KB of
-// 160) off the CU: the kernel is latency bound and runs 4x slower when its waves share SIMDs with MFMA waves.
-__global__ __launch_bounds__(POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
+// The LDS request (packed L, the product buffer of the inverse and the tile inverses: 99 KB / 116 KB) keeps every
+// tile-engine workgroup (72 KB of 160) off the CU: the kernel is latency bound and runs 4x slower when its waves share
+// SIMDs with MFMA waves.  MFMA = false: the earlier all-VALU form, kept for same-machine comparison (GPBO_POTRF_VALU=1).
+constexpr int POTRF_MFMA_THREADS = 1024;        // 16 waves: the MFMA phases are LDS-latency bound, four waves per SIMD hide it
+template <bool MFMA>
+__global__ __launch_bounds__(MFMA ? POTRF_MFMA_THREADS : POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
                                                               double* __restrict__ Dinv, int* __restrict__ info, BatchStride bs) {
-    __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES];
-    potrf_diag_body(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S);
+    __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + (MFMA ? 8 * LEAF_DOUBLES : 0)];
+    potrf_diag_body<MFMA>(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S);
 }
 
 // Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T

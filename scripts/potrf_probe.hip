@@ -4,20 +4,20 @@
 #include <cstdio>
 #include <vector>
 using namespace gpbo;
-int main() {
+template <bool MFMA> int run(int threads) {
     const int n = 128;
     std::vector<double> A(n * n);
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) A[i * n + j] = exp(-0.5 * (i - j) * (i - j) / 400.0) + (i == j ? 0.01 : 0.0);
     double *dA, *dinv; int* info;
     (void)hipMalloc(&dA, n * n * 8); (void)hipMalloc(&dinv, n * n * 8); (void)hipMalloc(&info, 64);
-    for (int rep = 0; rep < 5; ++rep) {
+    for (int rep = 0; rep < 3; ++rep) {
         (void)hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         (void)hipMemset(info, 0, 64);
         { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0);
-        k_potrf_diag<<<1, POTRF_THREADS>>>(dA, n, 0, dinv, info, BatchStride{});
+        k_potrf_diag<MFMA><<<1, threads>>>(dA, n, 0, dinv, info, BatchStride{});
         (void)hipEventRecord(e1);
         (void)hipDeviceSynchronize();
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -36,3 +36,4 @@ int main() {
     }
     return 0;
 }
+int main() { printf("--- VALU form\n"); run<false>(256); for (int th : {256, 512, 1024}) { printf("--- MFMA form, %d threads\n", th); run<true>(th); } return 0; }
