@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gpbo.h"
@@ -139,6 +140,27 @@ namespace {
     } while (0)
 
 int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// Wait for the context's stream, but not for ever: the two-stream factorisation chains waits between hardware queues, and
+// with more processes on the GPU than hardware queue slots such a chain can stop advancing.  The caller gets an error
+// after `seconds` (the work stays enqueued; the context should be destroyed).
+int sync_bounded(gpbo_ctx* ctx, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) return GPBO_OK;
+        if (e != hipErrorNotReady) {
+            ctx->err = std::string("stream query: ") + hipGetErrorString(e);
+            return GPBO_ERR_HIP;
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
+            ctx->err = "the two-stream factorisation (GPBO_CHOL_LOOKAHEAD=1) made no progress for " + std::to_string((int)seconds) +
+                       " s: the GPU is shared with other processes; unset GPBO_CHOL_LOOKAHEAD";
+            return GPBO_ERR_HIP;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
 
 hipEvent_t ev_get(gpbo_ctx* ctx) {
     if (ctx->pool_used == ctx->pool.size()) {
@@ -449,6 +471,7 @@ int launch_trsv(gpbo_ctx* ctx, const double* L, double eps_val, const double* ep
         std::vector<double> flags(S, 0.0);
         HIPCHK(hipMemcpy2DAsync(flags.data(), sizeof(double), ctx->params + P_REFINE, std::max<size_t>(ctx->bs.par, 1) * sizeof(double),
                                 sizeof(double), S, hipMemcpyDeviceToHost, ctx->stream));
+        if (getenv("GPBO_CHOL_LOOKAHEAD") && atoi(getenv("GPBO_CHOL_LOOKAHEAD")) != 0) CHK(sync_bounded(ctx, 120.0));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         bool any = false;
         for (double f : flags) any = any || f != 0.0;
@@ -979,6 +1002,8 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     int info = 0;
     HIPCHK(hipMemcpyAsync(par_out, ctx->params, sizeof(par_out), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (getenv("GPBO_CHOL_LOOKAHEAD") && atoi(getenv("GPBO_CHOL_LOOKAHEAD")) != 0)
+        CHK(sync_bounded(ctx, 30.0 + 1e-12 * (double)n * (double)n * (double)n));      // generous: 30 s + 1 s per Tflop of n^3
     HIPCHK(hipStreamSynchronize(ctx->stream));
     double ms[T_NCAT], cnt[T_NCAT];
     timing_collect(ctx, ms, cnt);
