@@ -1,7 +1,7 @@
 """MI355X-native GP posterior + acquisition hot path."""
 from ._lib import (ACQ_EI, ACQ_PI, ACQ_UCB, INCUMBENT_GIVEN, INCUMBENT_MAX_MU, INCUMBENT_MAX_Y, KERNEL_MATERN52,
-                   KERNEL_RBF, VARIANT_SINGLE, VARIANT_V4)
+                   KERNEL_RBF, VARIANT_M3, VARIANT_SINGLE, VARIANT_V4)
 from .gp import GP, GpboError
 
-__all__ = ['GP', 'GpboError', 'KERNEL_RBF', 'KERNEL_MATERN52', 'VARIANT_V4', 'VARIANT_SINGLE', 'ACQ_EI', 'ACQ_UCB',
+__all__ = ['GP', 'GpboError', 'KERNEL_RBF', 'KERNEL_MATERN52', 'VARIANT_V4', 'VARIANT_SINGLE', 'VARIANT_M3', 'ACQ_EI', 'ACQ_UCB',
            'ACQ_PI', 'INCUMBENT_MAX_MU', 'INCUMBENT_MAX_Y', 'INCUMBENT_GIVEN']

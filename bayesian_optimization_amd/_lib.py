@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('GPBO_LIBRARY') or os.path.join(_HERE, 'libgpbo.so')  
 
 OK, ERR_NOT_PD, ERR_BAD_ARG, ERR_HIP = 0, 1, 2, 3
 KERNEL_RBF, KERNEL_MATERN52 = 0, 1
-VARIANT_V4, VARIANT_SINGLE = 0, 1
+VARIANT_V4, VARIANT_SINGLE, VARIANT_M3 = 0, 1, 3
 ACQ_EI, ACQ_UCB, ACQ_PI = 0, 1, 2
 INCUMBENT_MAX_MU, INCUMBENT_MAX_Y, INCUMBENT_GIVEN = 0, 1, 2
 

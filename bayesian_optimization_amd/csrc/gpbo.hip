@@ -103,7 +103,7 @@ struct gpbo_ctx {
     // chunk scratch
     int64_t chunk_req = 0, chunk = 0, scratch_npad = 0;
     double *Bmat = nullptr, *partial = nullptr, *mupart = nullptr;
-    int kc = 512;
+    int kc = KS_ROWS;   // training rows per workgroup of the Ks build = rows per partial mean
 
     // reductions
     double *red_v = nullptr, *red_v2 = nullptr, *inc_dev = nullptr;
@@ -940,7 +940,7 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     if (!X || !y || !theta) BADARG("fit: null input");
     if (n <= 0 || d <= 0 || d > MAX_D) BADARG("fit: need n >= 1 and 1 <= d <= 32");
     if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN52) BADARG("fit: unknown kernel");
-    if (variant != GPBO_VARIANT_V4 && variant != GPBO_VARIANT_SINGLE) BADARG("fit: unknown variant");
+    if (variant != GPBO_VARIANT_V4 && variant != GPBO_VARIANT_SINGLE && variant != GPBO_VARIANT_M3) BADARG("fit: unknown variant");
     if (!(sigmaY >= 0)) BADARG("fit: sigmaY must be >= 0");
     for (int t = 0; t < d; ++t)
         if (!(theta[t] != 0.0) || !std::isfinite(theta[t])) BADARG("fit: theta entries must be finite and non-zero");
@@ -986,10 +986,15 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
         CHK(launch_trsv(ctx, ctx->bufA, ctx->eps));
         hipLaunchKernelGGL(k_fit_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bufA, (long)n_pad,
                            (const double*)ctx->yv, (const double*)ctx->alpha1, ctx->alpha, (int)n, (int)n_pad, variant, ctx->params, ctx->bs);
-        if (variant == GPBO_VARIANT_V4) {
+        if (variant == GPBO_VARIANT_V4 || variant == GPBO_VARIANT_M3) {
             CHK(launch_kernel_matrix(ctx, ctx->bufB, ctx->params + P_THETA1, ctx->eps));   // theta1*K0 + eps, :146-147
             CHK(launch_cholesky(ctx, ctx->bufB, ctx->info_dev));
             nchol += 1;
+            if (variant == GPBO_VARIANT_M3) {
+                // the MATLAB form takes alpha from the SECOND factor (GP/BayesOpt_v3.m:352-356): Mu = (theta1 Ks0) (theta1 K0 + eps)^-1 y
+                Scope s2(ctx, T_TRSV);
+                CHK(launch_trsv_vec(ctx, ctx->bufB, ctx->yv, ctx->alpha, false, nullptr));
+            }
             CHK(launch_inverse(ctx, ctx->bufB, ctx->bufW, ctx->bufA));
             ctx->bufL = ctx->bufB;
         } else {
@@ -1616,7 +1621,8 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
     if (lockstep) {
         size_t free_b = 0, total_b = 0;
         const double per_slot = 3.2 * 8.0 * (double)n_pad * (double)n_pad;
-        slots = std::min<int>(B, nb <= 16 ? 64 : (nb <= 32 ? 32 : (nb <= 64 ? 16 : 8)));
+        slots = std::min<int>(B, nb <= 16 ? 64 : (nb <= 32 ? 32 : (nb <= 128 ? 16 : 8)));      // n = 16384: 16 slots 13.8 settings/s, 8: 13.6, 32: 13.0
+        if (const char* e = getenv("GPBO_LML_SLOTS")) slots = std::min<int>(B, std::max(1, atoi(e)));
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             slots = (int)std::max(1.0, std::min((double)slots, std::floor(0.4 * (double)free_b / per_slot)));
         if (slots < 2) lockstep = false;

@@ -36,7 +36,10 @@ extern "C" {
 #define GPBO_KERNEL_MATERN52 1 /* (1+sqrt5 r+5r^2/3)exp(-sqrt5 r); no reference implementation */
 
 #define GPBO_VARIANT_V4 0      /* two-factor posterior, BayesOpt_v4.ipynb:142-151 */
-#define GPBO_VARIANT_SINGLE 1  /* single factor, theta1-scaled variance, GP/BayesOptFcn_v1.m:73-83 */
+#define GPBO_VARIANT_SINGLE 1  /* single factor, theta1-scaled variance, GP/BayesOptFcn_v1.m:73-83; the scaled-factor form of
+                                * GP/BayesOpt_v2.m:177-189 (L <- sqrt(theta1) L) is the same posterior analytically */
+#define GPBO_VARIANT_M3 3      /* MATLAB two-factor form, GP/BayesOpt_v3.m:343-360: variance as v4, mean with alpha taken from
+                                * the second factor, Mu = (theta1 Ks0)(theta1 K0 + eps)^-1 y (differs from v4 when sigmaY != 0) */
 
 #define GPBO_ACQ_EI 0          /* BayesOpt_v4.ipynb:188-197 */
 #define GPBO_ACQ_UCB 1         /* GP/BayesOpt_v1.m:248-251 */

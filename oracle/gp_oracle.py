@@ -35,6 +35,7 @@ MATERN52 = 1
 
 VARIANT_V4 = 0       # two-factor posterior of BayesOpt_v4.ipynb:142-151
 VARIANT_SINGLE = 1   # single-factor, theta1-scaled variance of GP/BayesOptFcn_v1.m:73-83
+VARIANT_M3 = 3       # MATLAB two-factor form of GP/BayesOpt_v3.m:343-360 (alpha from the second factor); text only, not runnable here
 
 
 # --------------------------------------------------------------------------- kernels
@@ -99,6 +100,11 @@ def fit(xTrain, yTrain, theta, sigmaY, kernel=RBF, variant=VARIANT_V4):
         L2 = np.linalg.cholesky(theta1 * K0 + eps * np.eye(n))   # :146-147
         st['L2'] = L2
         st['alpha'] = alpha1 / theta1                             # :148 (returned alpha)
+    elif variant == VARIANT_M3:
+        L2 = np.linalg.cholesky(theta1 * K0 + eps * np.eye(n))   # GP/BayesOpt_v3.m:350-351
+        a2 = solve_triangular(L2, y, lower=True)
+        st['L2'] = L2
+        st['alpha'] = solve_triangular(L2, a2, lower=True, trans='T')   # GP/BayesOpt_v3.m:352: alpha = L'\(L\y) with the second L
     else:
         st['L2'] = None
         st['alpha'] = alpha1
@@ -121,7 +127,7 @@ def predict(st, xTest, block=8192):
     for lo in range(0, m, block):
         hi = min(m, lo + block)
         Ks0 = kernel_matrix(Xs[lo:hi], st['X'], st['theta'], st['kernel'])   # (mb, n)
-        if st['variant'] == VARIANT_V4:
+        if st['variant'] in (VARIANT_V4, VARIANT_M3):
             Ks = th1 * Ks0
             mu[lo:hi] = Ks @ st['alpha']
             v = solve_triangular(st['L2'], Ks.T, lower=True)

@@ -39,6 +39,31 @@ __global__ __launch_bounds__(256) void ks_direct(const double* __restrict__ Xs, 
     }
 }
 
+// direct, training rows staged in LDS (row-major [512][D]: one broadcast ds_read_b128 per two coordinates), loop unrolled by 4
+template <int D>
+__global__ __launch_bounds__(256) void ks_direct_lds(const double* __restrict__ Xs, const double* __restrict__ Xtr, int n,
+                                                     double* __restrict__ B, long ldb, int kernel) {
+    __shared__ double xr[512 * D];
+    const int tid = threadIdx.x;
+    const int k_lo = blockIdx.y * 512;
+    for (int idx = tid; idx < 512 * D; idx += 256) xr[idx] = Xtr[(long)k_lo * D + idx];
+    __syncthreads();
+    const long j = (long)blockIdx.x * 256 + tid;
+    double xs[D];
+#pragma unroll
+    for (int t = 0; t < D; ++t) xs[t] = Xs[j * D + t];
+#pragma unroll 4
+    for (int k = 0; k < 512; ++k) {
+        double Dq = 0.0;
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+            const double df = xs[t] - xr[k * D + t];
+            Dq += df * df;
+        }
+        B[(long)(k_lo + k) * ldb + j] = kern_eval(Dq, kernel);
+    }
+}
+
 // gemm: a wave owns 16 candidates (operand B of the MFMA, loaded once) and walks the training rows 16 at a time;
 // the rows' coordinates and norms come from LDS (512 rows per workgroup).  Xtr: [n][D] scaled (row-major).
 template <int D>
@@ -108,12 +133,13 @@ void run(const char* name, int n, int m, double theta, int kernel) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     std::vector<double> out((size_t)n * m);
-    for (int form = 0; form < 2; ++form) {
+    for (int form = 0; form < 3; ++form) {
         float best = 1e30f;
         for (int rep = 0; rep < 5; ++rep) {
             (void)hipEventRecord(e0);
             if (form == 0) hipLaunchKernelGGL(ks_direct<D>, dim3(m / 256, n / 512), dim3(256), 0, 0, dXs, dXt, n, dB, (long)m, kernel);
-            else hipLaunchKernelGGL(ks_gemm<D>, dim3(m / 64, n / 512), dim3(256), 0, 0, dXs, dX, n, dB, (long)m, kernel);
+            else if (form == 1) hipLaunchKernelGGL(ks_gemm<D>, dim3(m / 64, n / 512), dim3(256), 0, 0, dXs, dX, n, dB, (long)m, kernel);
+            else hipLaunchKernelGGL(ks_direct_lds<D>, dim3(m / 256, n / 512), dim3(256), 0, 0, dXs, dX, n, dB, (long)m, kernel);
             (void)hipEventRecord(e1);
             (void)hipDeviceSynchronize();
             float ms;
@@ -137,7 +163,7 @@ void run(const char* name, int n, int m, double theta, int kernel) {
             erel = fmax(erel, err / (double)ref);
         }
         printf("%s %-6s: %8.3f ms per %d x %d panel, %7.1f GB/s written, max abs err %.2e, max rel err %.2e (%.1f ulp of 1)\n", name,
-               form ? "gemm" : "direct", best, n, m, 8.0 * n * m / (best * 1e-3) / 1e9, emax, erel, emax / 1.11e-16);
+               form == 0 ? "direct" : form == 1 ? "gemm" : "dirlds", best, n, m, 8.0 * n * m / (best * 1e-3) / 1e9, emax, erel, emax / 1.11e-16);
     }
     (void)hipFree(dX); (void)hipFree(dXt); (void)hipFree(dXs); (void)hipFree(dB);
 }

@@ -68,7 +68,8 @@ def test_ragged_shapes_against_oracle(gp0, n, d, m):
 
 
 @pytest.mark.parametrize('kernel,variant', [(bo.KERNEL_MATERN52, bo.VARIANT_V4), (bo.KERNEL_RBF, bo.VARIANT_SINGLE),
-                                            (bo.KERNEL_MATERN52, bo.VARIANT_SINGLE)])
+                                            (bo.KERNEL_MATERN52, bo.VARIANT_SINGLE), (bo.KERNEL_RBF, bo.VARIANT_M3),
+                                            (bo.KERNEL_MATERN52, bo.VARIANT_M3)])
 def test_matern_and_single_factor_variants(gp0, kernel, variant):
     # no reference implementation for Matern-5/2: pinned against the oracle, which shares all code but the epilogue
     X, y, Xs = synth(500, 4, 3000, 21)

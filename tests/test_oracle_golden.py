@@ -221,3 +221,21 @@ def test_reference_values_of_the_ill_conditioned_case_are_defined_to_about_5e_7(
     assert r['cond'] > 1e11
     assert min(t for t, _ in moves) > 1e-7 and min(a for _, a in moves) > 3e-7
     assert max(t for t, _ in moves) < ILL_TOL_VAR and max(a for _, a in moves) < ILL_TOL_MU
+
+
+def test_matlab_two_factor_variant_differs_from_v4_only_through_the_unscaled_noise():
+    """GP/BayesOpt_v3.m:343-360 takes alpha from the second factor: Mu = theta1 Ks0 (theta1 K0 + eps)^-1 y.  With eps -> 0 that is
+    v4's mean; with sigmaY != 0 it is not (eps is not rescaled by theta1), while the variance is v4's in both cases."""
+    g = golden('g3_d4_n64_s1e-1')
+    mu4, var4, _ = o.gprfcn_diag(g['xTest'], g['xTrain'], g['yTrain'], g['theta'], 0.1, variant=o.VARIANT_V4)
+    mu3, var3, st = o.gprfcn_diag(g['xTest'], g['xTrain'], g['yTrain'], g['theta'], 0.1, variant=o.VARIANT_M3)
+    assert np.array_equal(var3, var4) and relmax(mu3, mu4) > 1e-4
+    K0 = o.kernel_matrix(g['xTrain'], g['xTrain'], g['theta'])
+    Ks0 = o.kernel_matrix(g['xTest'], g['xTrain'], g['theta'])
+    th1 = st['theta1']
+    direct = th1 * Ks0 @ np.linalg.solve(th1 * K0 + 0.01 * np.eye(64), g['yTrain'].reshape(-1))
+    assert relmax(mu3, direct) <= 1e-11
+    g0 = golden('g3_d4_n64_s0')
+    a, _, _ = o.gprfcn_diag(g0['xTest'], g0['xTrain'], g0['yTrain'], g0['theta'], 0.0, variant=o.VARIANT_V4)
+    b, _, _ = o.gprfcn_diag(g0['xTest'], g0['xTrain'], g0['yTrain'], g0['theta'], 0.0, variant=o.VARIANT_M3)
+    assert relmax(a, b) <= 1e-6
