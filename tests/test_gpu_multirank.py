@@ -122,3 +122,26 @@ print('RCCL_OK')
     err = open(os.path.join(logdir, 'rccl_single.err')).read()
     assert proc.returncode == 0, err[-2000:]
     assert 'RCCL_OK' in open(os.path.join(logdir, 'rccl_single.out')).read()
+
+
+def test_two_rank_strong_scaling_splits_one_candidate_set(gp0):
+    """--scaling strong: ONE candidate set (odd size: the ranks' blocks differ by one) split over two ranks; argmax, EI and
+    max(Mu) equal one process sweeping the whole set."""
+    from bayesian_optimization_amd import synth
+    m_total, n = 100001, 2048
+    env = dict(os.environ, GPBO_DIST_BACKEND='gloo', GPBO_FORCE_DEVICE='0', MASTER_ADDR='127.0.0.1', GPBO_STALL_DUMP='60')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--config', 'cfg3',
+           '--scaling', 'strong', '--candidates', str(m_total), '--n-train', str(n)]
+    out = _run(cmd, env, 'two_rank_strong')
+    res = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
+    assert res['n_gpus'] == 2 and res['ranks_seen'] == 2 and res['scaling'] == 'strong'
+    assert res['config']['candidates_total'] == m_total and res['config']['candidates_per_gpu'] in (m_total // 2, m_total // 2 + 1)
+    cfg = dict(synth.CONFIGS['cfg3'], n=n)
+    X, y, theta = synth.training_set(cfg)
+    gp0.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
+    gp0.set_candidates(synth.candidates(cfg, 0, m_total))
+    mu_max = gp0.posterior()
+    idx, best = gp0.acquire(0, cfg['kappa'])
+    assert res['argmax']['index'] == idx and res['argmax']['ei'] == best and res['argmax']['mu_max'] == mu_max
