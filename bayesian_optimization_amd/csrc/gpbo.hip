@@ -592,7 +592,20 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                 const int nj = (int)(cols / TN);
                 int cg = std::min(nj, 128);   // column blocks per tile-order group
                 if (const char* e = getenv("GPBO_TRMM_COLGROUP")) cg = std::max(1, std::min(nj, atoi(e)));
-                if (keep_v)
+                static const bool wide = getenv("GPBO_TRMM_WIDE") && atoi(getenv("GPBO_TRMM_WIDE")) != 0;
+                if (wide) {
+                    const int nj2 = (int)(cols / WIDE_N);
+                    int cg2 = std::min(nj2, 64);
+                    if (const char* e = getenv("GPBO_TRMM_COLGROUP")) cg2 = std::max(1, std::min(nj2, atoi(e)));
+                    if (keep_v)
+                        hipLaunchKernelGGL(k_trmm_sumsq_wide<true>, dim3((unsigned)(nb * nj2)), dim3(WIDE_THREADS), 0, ctx->stream,
+                                           (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
+                                           ctx->partial, nb, nj2, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n, cg2);
+                    else
+                        hipLaunchKernelGGL(k_trmm_sumsq_wide<false>, dim3((unsigned)(nb * nj2)), dim3(WIDE_THREADS), 0, ctx->stream,
+                                           (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
+                                           ctx->partial, nb, nj2, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0, cg2);
+                } else if (keep_v)
                     hipLaunchKernelGGL((mode == 2 ? k_trmm_sumsq<true, 2> : mode == 1 ? k_trmm_sumsq<true, 1> : k_trmm_sumsq<true, 0>), dim3((unsigned)(nb * nj)),
                                        dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,

@@ -1198,6 +1198,57 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __
     if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
 }
 
+// The same product on 128 x 256 tiles (gemm_tile_128x256; 512 threads).  nj2 = column blocks of 256.
+template <bool STORE_V>
+__global__ __launch_bounds__(WIDE_THREADS, 1) void k_trmm_sumsq_wide(const double* __restrict__ W, long ld,
+                                                                     const double* __restrict__ Bmat, long ldb,
+                                                                     double* __restrict__ partial, int nb, int nj2,
+                                                                     double* __restrict__ Vres, long ldv, long j0, long m, int v_rows,
+                                                                     int cg) {
+    const int per = nb * cg;
+    const int grp = blockIdx.x / per, r = blockIdx.x % per;
+    const int cw = min(cg, nj2 - grp * cg);
+    const int ib = nb - 1 - r / cw;
+    const int jb = grp * cg + r % cw;
+    __shared__ double lds[WIDE_LDS_DOUBLES];
+    f64x4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128x256(W + (long)ib * PB * ld, ld, Bmat + (long)jb * WIDE_N, ldb, 0, (ib + 1) * PB, acc, lds, ib * PB);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 2, wc = w & 3;
+    if (STORE_V) {
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int row = ib * PB + wr * 64 + ta * 16 + (lane >> 4) + 4 * r4;
+                    const long col = j0 + (long)jb * WIDE_N + wc * 64 + tb * 16 + (lane & 15);
+                    if (row < v_rows && col < m) Vres[(long)row * ldv + col] = acc[ta][tb][r4];
+                }
+    }
+    double cs[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+        double s = 0.0;
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) s += acc[ta][tb][r4] * acc[ta][tb][r4];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        cs[tb] = s;
+    }
+    double* red = lds;   // the tile engine ended on a barrier: LDS is free
+    if ((lane >> 4) == 0) {
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) red[wr * WIDE_N + wc * 64 + tb * 16 + lane] = cs[tb];
+    }
+    __syncthreads();
+    if (tid < WIDE_N) partial[(long)ib * ldb + (long)jb * WIDE_N + tid] = red[tid] + red[WIDE_N + tid];
+}
+
 // Trend basis of the kriging flavour (polymat, Gaussian_Process_Regression.ipynb:113-140): columns for
 // C = 1..3 inputs and degree 0..3, in the reference's column order.  Returns f(x) . beta.
 __device__ __forceinline__ double trend_eval(const double* __restrict__ x, int C, int deg, const double* __restrict__ beta) {
