@@ -1673,7 +1673,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         if (e_ != hipSuccess) return fail_hip(#expr, e_);  \
     } while (0)
     // batch arrays on the caller context, grown on demand (their addresses are part of the lanes' graph keys)
-    const size_t need_x = (size_t)d * n_pad, need_b = (size_t)B, need_bd = (size_t)B * d;
+    const size_t need_x = (size_t)(d + 1) * n_pad, need_b = (size_t)B, need_bd = (size_t)B * d;
     if (ctx->lb_xraw_cap < need_x) {
         if (ctx->lb_xraw) hipFree(ctx->lb_xraw);
         ctx->lb_xraw = nullptr;
@@ -1756,17 +1756,20 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         }
     }
     {
-        std::vector<double> xr((size_t)d * n_pad, 0.0), yp(n_pad, 0.0);
+        // one staged upload: the d padded coordinate rows, then the padded y as row d; the slots' copies of y are
+        // made on the device
+        std::vector<double> xr((size_t)(d + 1) * n_pad, 0.0);
         for (int t = 0; t < d; ++t)
             for (int64_t i = 0; i < n; ++i) xr[(size_t)t * n_pad + i] = X[i * d + t];
-        for (int64_t i = 0; i < n; ++i) yp[i] = y[i];
+        for (int64_t i = 0; i < n; ++i) xr[(size_t)d * n_pad + i] = y[i];
         LCHK(hipMemcpy(ctx->lb_xraw, xr.data(), xr.size() * 8, hipMemcpyHostToDevice));
-        for (int l = 0; l < lanes; ++l)
-            for (int sidx = 0; sidx < lane[l]->batch; ++sidx)
-                LCHK(hipMemcpy(lane[l]->yv + (size_t)sidx * n_pad, yp.data(), yp.size() * 8, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(ctx->lb_th, thetas, (size_t)B * d * 8, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(ctx->lb_sg, sigmas, (size_t)B * 8, hipMemcpyHostToDevice));
         LCHK(hipDeviceSynchronize());
+        for (int l = 0; l < lanes; ++l)
+            hipLaunchKernelGGL(k_replicate_vec, dim3((unsigned)((n_pad + 255) / 256), (unsigned)lane[l]->batch), dim3(256), 0,
+                               lane[l]->stream, (const double*)(ctx->lb_xraw + (size_t)d * n_pad), lane[l]->yv, (int)n_pad);
+        LCHK(hipGetLastError());
     }
     // the launch sequence of one setting per slot of context c; every argument is the same for every setting
     auto enqueue_setting = [&](gpbo_ctx* c) -> int {

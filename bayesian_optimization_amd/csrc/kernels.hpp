@@ -1774,6 +1774,12 @@ __global__ void k_pick_setting(int b0, int B, const double* __restrict__ thetas,
     }
 }
 
+// every slot's observation vector is the same padded y: dst[s*n_pad + i] = src[i], s = blockIdx.y
+__global__ __launch_bounds__(256) void k_replicate_vec(const double* __restrict__ src, double* __restrict__ dst, int n_pad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_pad) dst[(long)blockIdx.y * n_pad + i] = src[i];
+}
+
 // b = slot->cur: out_nll[b] = -logL (NaN when the factorisation failed), out_grad[b*d + t] = -1/2 * sum_tiles gpart / theta_t,
 // out_info[b] = the factorisation status
 __global__ __launch_bounds__(256) void k_lml_store(const double* __restrict__ params, const LmlSlot* __restrict__ slot,
