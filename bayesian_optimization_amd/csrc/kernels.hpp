@@ -455,13 +455,26 @@ constexpr int LEAF_P = 17;                        // pitch of a 16x16 tile inver
 constexpr int LEAF_DOUBLES = 16 * LEAF_P;
 
 // Wave-level: Cholesky factor of the 16x16 tile at (c0, c0) of the packed block M, written back in place, and its
-// inverse into Wi[i * LEAF_P + c].  Returns the first failing column (pivot <= 0 or NaN) or -1.  Lanes >= 16 idle along.
+// inverse into Wi[r * LEAF_P + c].  Returns the first failing column (pivot <= 0 or NaN) or -1.
+// The elimination runs on the 32x16 matrix [A; I]: lanes 0..15 hold the rows of A, lanes 16..31 the rows of the identity.
+// A row below the diagonal tile leaves an elimination as row * inv(L)^T, so lane 16 + m ends with row m of inv(L)^T,
+// i.e. column m of the inverse, from the very instructions that factor A.  Lanes >= 32 idle along.
 __device__ __forceinline__ int leaf_potrf_inv(double* __restrict__ M, int c0, double* __restrict__ Wi) {
     const int lane = threadIdx.x & 63;
-    const int i = lane & 15;
-    double v[16], rdv[16];
+    const int i = lane & 31;                       // row of [A; I]
+    double v[16];
+    {
+        // all sixteen reads are issued before the first is used (every lane reads a valid address; the empty asm keeps
+        // the compiler from sinking the reads into the selects below, which would serialise sixteen LDS round trips)
+        const int r = i & 15;
+        const double* row = M + tri_off(c0 + r) + c0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) v[c] = (c <= i) ? M[tri_off(c0 + i) + c0 + c] : 0.0;
+        for (int c = 0; c < 16; ++c) v[c] = row[c <= r ? c : r];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(v[c]));
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = (i < 16) ? ((c <= i) ? v[c] : 0.0) : ((c == i - 16) ? 1.0 : 0.0);
+    }
     int fail = -1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -473,7 +486,6 @@ __device__ __forceinline__ int leaf_potrf_inv(double* __restrict__ M, int c0, do
         rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
         double d = piv * rd;
         d = fma(0.5 * rd, fma(-d, d, piv), d);
-        rdv[j] = rd;
         const double lij = (i > j) ? v[j] * rd : 0.0;
         v[j] = (i == j) ? d : lij;                 // rows above the diagonal hold zero in this column
 #pragma unroll
@@ -486,39 +498,34 @@ __device__ __forceinline__ int leaf_potrf_inv(double* __restrict__ M, int c0, do
 #pragma unroll
         for (int c = 0; c < 16; ++c)
             if (c <= i) M[tri_off(c0 + i) + c0 + c] = v[c];
-    }
-    // inverse, column-wise: lane c solves L w = e_c by forward substitution; L[r][k] = row r's register k, uniform
-    double w[16];
+    } else if (lane < 32) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        double acc = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) acc = fma(-readlane_f64(v[k], r), w[k], acc);
-        w[r] = acc * rdv[r];
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Wi[r * LEAF_P + i] = w[r];
+        for (int r = 0; r < 16; ++r) Wi[r * LEAF_P + (i - 16)] = v[r];
     }
     return fail;
 }
 
 // Factor of the packed 128x128 block M in place; Wi8: [8][LEAF_DOUBLES] receives the inverses of the eight diagonal tiles.
-// All 256 threads must call it; ends on a barrier.
+// Per 16-column panel: the rows below the diagonal tile are multiplied by its inverse, then the trailing triangle is
+// updated.  The next diagonal tile is updated first, by wave 0, which goes on to factor it while the other waves
+// update the rest of the triangle: the tile factorisation (one wave, a chain of 16 pivots) is the critical path, and
+// this way only the small row-scaling phase stands between two of them.  All threads must call it; ends on a barrier.
 __device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __restrict__ Wi8, int* __restrict__ failp) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    for (int jb = 0; jb < 8; ++jb) {
+    auto leaf = [&](int jb) {
+        const int fail = leaf_potrf_inv(M, 16 * jb, Wi8 + jb * LEAF_DOUBLES);
+        if (lane == 0 && fail >= 0 && *failp < 0) *failp = fail;
+    };
+    GPBO_STAMP(0, 0);
+    if (w == 0) leaf(0);
+    GPBO_STAMP(1, 1);
+    __syncthreads();
+    for (int jb = 0; jb < 7; ++jb) {
         const int c0 = 16 * jb;
-        double* Wi = Wi8 + jb * LEAF_DOUBLES;
-        GPBO_STAMP(0, 0);
-        if (w == 0) {
-            const int fail = leaf_potrf_inv(M, c0, Wi);
-            if (lane == 0 && fail >= 0 && *failp < 0) *failp = fail;
-        }
-        __syncthreads();
-        GPBO_STAMP(1, 1);
+        const double* Wi = Wi8 + jb * LEAF_DOUBLES;
         const int nt = 7 - jb;                       // 16-row tiles below the diagonal tile
+        GPBO_STAMP(0, 0);
         // rows below: X = A[rows, c0:c0+16] * inv(L11)^T, one tile per wave and turn
         for (int t = w; t < nt; t += nw) {
             const int r0 = c0 + 16 + 16 * t;
@@ -534,9 +541,10 @@ __device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __
         }
         __syncthreads();
         GPBO_STAMP(2, 1);
-        // trailing triangle: A[I, J] -= X_I X_J^T over the tile pairs I >= J
+        // trailing triangle: A[I, J] -= X_I X_J^T over the tile pairs I >= J; pair 0 is the next diagonal tile
         const int npair = nt * (nt + 1) / 2;
-        for (int pr = w; pr < npair; pr += nw) {
+        const int first = (w == 0) ? 0 : w, step = (nw > 1) ? nw - 1 : 1;
+        for (int pr = first; pr < npair; pr = (pr == 0 && nw > 1) ? npair : pr + step) {
             int ti, tj;
             tri_decode(pr, ti, tj);
             const int rI = c0 + 16 + 16 * ti, rJ = c0 + 16 + 16 * tj;
@@ -552,6 +560,15 @@ __device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __
                 const int row = rI + lk + 4 * r, col = rJ + li;
                 if (col <= row) M[tri_off(row) + col] -= acc[r];
             }
+        }
+        if (w == 0) {
+            // the tile this wave just updated is read back by the same wave: LDS serves a wave's requests in order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            GPBO_STAMP(0, 0);
+            leaf(jb + 1);
+            GPBO_STAMP(1, 1);
         }
         __syncthreads();
         GPBO_STAMP(3, 1);
@@ -624,6 +641,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     double* blk = A + (long)p * PB * ld + (long)p * PB;
     double* Tbuf = S + POTRF_LDS_PACKED;
     double* Wi8 = Tbuf + TRINV_T_DOUBLES;          // only the MFMA form has (and uses) this space
+    GPBO_STAMP(8, 0);
     if (tid == 0) fail_s = -1;
     for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {      // lower triangle -> packed LDS
         const int r = idx >> 6, c = (idx & 63) * 2;
@@ -634,10 +652,10 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
         }
     }
     __syncthreads();
-    GPBO_STAMP(4, 0);
+    GPBO_STAMP(4, 1);
     if (MFMA) potrf128_mfma(S, Wi8, &fail_s);
     else potrf128_lds(S, &fail_s);
-    GPBO_STAMP(5, 0);
+    GPBO_STAMP(5, 1);
     if (tid == 0 && fail_s >= 0) atomicCAS(info, 0, p * PB + fail_s + 1);
     for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {      // L -> global, zeros above the diagonal
         const int r = idx >> 6, c = (idx & 63) * 2;
@@ -659,6 +677,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
         v.y = (c + 1 <= r) ? S[tri_off(r) + c + 1] : 0.0;
         *reinterpret_cast<f64x2*>(dinv + r * PB + c) = v;
     }
+    GPBO_STAMP(9, 1);
 }
 
 // The LDS request (packed L, the product buffer of the inverse and the tile inverses: 99 KB / 116 KB) keeps every

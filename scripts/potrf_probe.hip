@@ -31,7 +31,7 @@ template <bool MFMA> int run(int threads) {
                 for (int k = 0; k < n; ++k) { s1 += L[i * n + k] * L[j * n + k]; s2 += W[i * n + k] * L[k * n + j]; }
                 e1m = fmax(e1m, fabs(s1 - A[i * n + j])); e2m = fmax(e2m, fabs(s2 - (i == j)));
             }
-        { long long z[64]; (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_stamps), sizeof(z)); printf("ticks(100MHz): potrf16 %lld trsm %lld update %lld storeL %lld inverse %lld\n", z[1], z[2], z[3], z[6], z[7]); }
+        { long long z[64]; (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_stamps), sizeof(z)); printf("ticks(100MHz): load %lld potrf16 %lld trsm %lld update %lld storeL %lld inverse %lld storeW %lld\n", z[4], z[1], z[2], z[3], z[6], z[7], z[9]); }
         printf("event %.1f us  |LL^T - A| %.2e  |WL - I| %.2e\n", ms * 1e3, e1m, e2m);
     }
     return 0;
