@@ -305,20 +305,41 @@ int chol_group(int nb) {
     return nb >= 192 ? 8 : 4;      // large n: a longer K makes the bulk update more efficient
 }
 
+// Panel solve: one wave per 16 rows (k_trsm_rows) while every wave gets a SIMD of its own (8 waves per block row, 1024
+// SIMDs); beyond that the 128-tile engine, which shares the inverted block through LDS, is faster (measured at
+// n = 32768).  The row form needs only the inverses of the 16x16 diagonal tiles, so for those panels the diagonal-block
+// kernel stops after the factor ("deferred") and k_trinv_diag forms the block inverses after the factorisation, all in
+// one launch, off the critical path.  Panels from chol_first_deferred(nb) on are deferred.
+bool chol_potrf_valu() {
+    static const bool v = getenv("GPBO_POTRF_VALU") && atoi(getenv("GPBO_POTRF_VALU")) != 0;
+    return v;
+}
+int chol_first_deferred(int nb) {
+    static const int trsm_rows_max = getenv("GPBO_TRSM_ROWS_MAX") ? atoi(getenv("GPBO_TRSM_ROWS_MAX")) : 128;
+    if (chol_potrf_valu()) return nb;              // the all-VALU diagonal kernel (comparison runs) always inverts in place
+    return std::max(0, nb - 1 - trsm_rows_max);
+}
+
 // F(group): the latency-bound part.  Needs the group's block columns up to date.
 void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, int p0, int g) {
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
-    static const bool potrf_valu = getenv("GPBO_POTRF_VALU") && atoi(getenv("GPBO_POTRF_VALU")) != 0;
     static const int potrf_threads = getenv("GPBO_POTRF_THREADS") ? atoi(getenv("GPBO_POTRF_THREADS")) : POTRF_MFMA_THREADS;
+    const int first_deferred = chol_first_deferred(nb);
     for (int q = p0; q < p0 + g; ++q) {
         const unsigned S = (unsigned)ctx->batch;
-        if (potrf_valu)
-            hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs);
+        const int defer = q >= first_deferred;
+        if (chol_potrf_valu())
+            hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, 0);
         else
-            hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1, 1, S), dim3(potrf_threads), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs);
-        if (q + 1 < nb)
-            hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1, 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
+            hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1, 1, S), dim3(potrf_threads), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs,
+                               defer);
+        if (q + 1 < nb) {
+            if (defer)
+                hipLaunchKernelGGL(k_trsm_rows, dim3(8 * (nb - q - 1), 1, S), dim3(64), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
+            else
+                hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1, 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
+        }
         const int rest = p0 + g - 1 - q;      // the group's block columns right of q take panel q at once (K = 128):
         if (rest > 0)                         // more tiles per launch and a shorter chain than one growing-K update per column
             hipLaunchKernelGGL(k_syrk_update<false>, dim3(rest, nb - q - 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q + 1, q + 1, q * PB, PB,
@@ -427,6 +448,10 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
                                    ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
         }
     }
+    const int first_deferred = chol_first_deferred(nb);
+    if (first_deferred < nb)
+        hipLaunchKernelGGL(k_trinv_diag, dim3((unsigned)(nb - first_deferred), 1, (unsigned)ctx->batch), dim3(1024), 0, ctx->stream,
+                           (const double*)A, ld, first_deferred, ctx->Dinv, ctx->bs);
     dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4), (unsigned)ctx->batch);
     hipLaunchKernelGGL(k_zero_upper, grid, dim3(256), 0, ctx->stream, A, (int)ctx->n_pad, ctx->bs);
     HIPCHK(hipGetLastError());

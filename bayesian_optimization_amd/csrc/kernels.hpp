@@ -633,9 +633,11 @@ __device__ __forceinline__ void trinv128_mfma(double* __restrict__ M, const doub
     trinv_level_mfma<64>(M, T);
 }
 
+// defer (MFMA form only): stop after the factor; the inverses of the eight 16x16 diagonal tiles go into the diagonal
+// tiles of the block's Dinv (all k_trsm_rows needs), the inverse of the whole block is left to k_trinv_diag.
 template <bool MFMA>
 __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
-                                                int* __restrict__ info, double* __restrict__ S) {
+                                                int* __restrict__ info, double* __restrict__ S, bool defer) {
     __shared__ int fail_s;
     const int tid = threadIdx.x;
     double* blk = A + (long)p * PB * ld + (long)p * PB;
@@ -664,12 +666,20 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
         v.y = (c + 1 <= r) ? S[tri_off(r) + c + 1] : 0.0;
         *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
     }
+    double* dinv = Dinv + (long)p * PB * PB;
+    if (MFMA && defer) {
+        for (int idx = tid; idx < 8 * 256; idx += blockDim.x) {
+            const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
+            dinv[(16 * b + r) * PB + 16 * b + c] = (c <= r) ? Wi8[b * LEAF_DOUBLES + r * LEAF_P + c] : 0.0;
+        }
+        GPBO_STAMP(6, 1);
+        return;
+    }
     __syncthreads();
     GPBO_STAMP(6, 1);
     if (MFMA) trinv128_mfma(S, Wi8, Tbuf);
     else trinv128_lds(S, Tbuf);
     GPBO_STAMP(7, 1);
-    double* dinv = Dinv + (long)p * PB * PB;
     for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
         const int r = idx >> 6, c = (idx & 63) * 2;
         f64x2 v;
@@ -686,9 +696,10 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
 constexpr int POTRF_MFMA_THREADS = 1024;        // 16 waves: the MFMA phases are LDS-latency bound, four waves per SIMD hide it
 template <bool MFMA>
 __global__ __launch_bounds__(MFMA ? POTRF_MFMA_THREADS : POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
-                                                              double* __restrict__ Dinv, int* __restrict__ info, BatchStride bs) {
+                                                              double* __restrict__ Dinv, int* __restrict__ info, BatchStride bs,
+                                                              int defer) {
     __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + (MFMA ? 8 * LEAF_DOUBLES : 0)];
-    potrf_diag_body<MFMA>(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S);
+    potrf_diag_body<MFMA>(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S, defer != 0);
 }
 
 // Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T
@@ -710,6 +721,94 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_panel(double* __restri
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ap[(long)acc_row(ta, r) * ld + acc_col(tb)] = acc[ta][tb][r];
+}
+
+// Panel solve without LDS, one wave per 16 rows of the panel: X L_pp^T = A[rows, p], solved as L_pp X^T = A^T by block
+// forward substitution over the eight 16x16 tiles of L_pp,
+//   X^T_j = inv(L_jj) (A^T_j - sum_{k<j} L_jk X^T_k),
+// every operand fragment read straight from global memory (L2) into registers, all reads of a wave in flight at once.
+// The 128-tile engine pays one memory round trip per 16 k-values, eight in a row at K = 128, and the panel solve sits on
+// the factorisation's critical path with at most nb - 1 workgroups; here eight times as many SIMDs work, nothing waits
+// on LDS or barriers, and only the inverses of the 16x16 diagonal tiles are needed (the diagonal tiles of Dinv), so the
+// inverse of the whole block can be formed off the critical path.
+// v_mfma_f64_16x16x4: A operand lane l = A[l & 15][kk], B operand = B[kk][l & 15], kk = l >> 4; result element r of lane
+// l = D[(l >> 4) + 4 r][l & 15].  A result feeds the next product as B operand without leaving its registers: in
+// sub-step r lane l offers row (l >> 4) + 4 r, so the A operand of that sub-step is read at k = (l >> 4) + 4 r (the
+// order of the k-sum is free).  The tiles are kept negated (nx = -X^T) so that the sum accumulates onto A^T.
+__global__ __launch_bounds__(64) void k_trsm_rows(double* __restrict__ A, long ld, int p, const double* __restrict__ Dinv,
+                                                 BatchStride bs) {
+    A += blockIdx.z * bs.mat;
+    const double* Wd = Dinv + blockIdx.z * bs.dinv + (long)p * PB * PB;
+    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    const double* Lb = A + (long)p * PB * ld + (long)p * PB;
+    double* rows = A + ((long)(p + 1) * PB + 16 * (long)blockIdx.x) * ld + (long)p * PB;
+    f64x4 st[8];                                   // A^T tiles: element r = A[row li][16 j + lk + 4 r]
+    double lf[28][4], wf[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[j][r] = rows[(long)li * ld + 16 * j + lk + 4 * r];
+            wf[j][r] = Wd[(16 * j + li) * PB + 16 * j + lk + 4 * r];
+        }
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < j; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lf[j * (j - 1) / 2 + k][r] = Lb[(long)(16 * j + li) * ld + 16 * k + lk + 4 * r];
+    f64x4 x[8], nx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f64x4 sacc = st[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(lf[j * (j - 1) / 2 + k][r], nx[k][r], sacc, 0, 0, 0);
+        f64x4 xa = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xa = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[j][r], sacc[r], xa, 0, 0, 0);
+        x[j] = xa;
+        nx[j] = -xa;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rows[(long)li * ld + 16 * j + lk + 4 * r] = x[j][r];
+}
+
+// Inverse of factored diagonal blocks p0 + blockIdx.x, from L (in A) and the tile inverses (diagonal tiles of Dinv),
+// for the blocks whose factorisation kernel left it out (it is not needed by k_trsm_rows).
+__global__ __launch_bounds__(1024) void k_trinv_diag(const double* __restrict__ A, long ld, int p0, double* __restrict__ Dinv,
+                                                    BatchStride bs) {
+    __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES];
+    const int tid = threadIdx.x, p = p0 + blockIdx.x;
+    const double* blk = A + blockIdx.z * bs.mat + (long)p * PB * ld + (long)p * PB;
+    double* dinv = Dinv + blockIdx.z * bs.dinv + (long)p * PB * PB;
+    double* Tbuf = S + POTRF_LDS_PACKED;
+    double* Wi8 = Tbuf + TRINV_T_DOUBLES;
+    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
+        const int r = idx >> 6, c = (idx & 63) * 2;
+        if (c <= r) {
+            const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)r * ld + c);
+            S[tri_off(r) + c] = v.x;
+            if (c + 1 <= r) S[tri_off(r) + c + 1] = v.y;
+        }
+    }
+    for (int idx = tid; idx < 8 * 256; idx += blockDim.x) {
+        const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
+        Wi8[b * LEAF_DOUBLES + r * LEAF_P + c] = dinv[(16 * b + r) * PB + 16 * b + c];
+    }
+    __syncthreads();
+    trinv128_mfma(S, Wi8, Tbuf);
+    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
+        const int r = idx >> 6, c = (idx & 63) * 2;
+        f64x2 v;
+        v.x = (c <= r) ? S[tri_off(r) + c] : 0.0;
+        v.y = (c + 1 <= r) ? S[tri_off(r) + c + 1] : 0.0;
+        *reinterpret_cast<f64x2*>(dinv + r * PB + c) = v;
+    }
 }
 
 // Trailing update with a group of solved panels: A[ib, jb] -= P[ib] * P[jb]^T,
@@ -735,19 +834,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restr
     __shared__ double lds[GEMM_LDS_DOUBLES];
     const double* Pi = A + (long)ib * PB * ld + kcol0;
     const double* Pj = A + (long)jb * PB * ld + kcol0;
+    // The accumulators start at -C and the tile is stored as -(acc): the read of C then travels with the first operand
+    // loads instead of standing as a second memory round trip after the product (sign flips are exact).
     f64x4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_128<true, true>(Pi, ld, Pj, ld, 0, klen, acc, lds);
     double* C = A + (long)ib * PB * ld + (long)jb * PB;
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* c = C + (long)acc_row(ta, r) * ld + acc_col(tb);
-                *c -= acc[ta][tb][r];
-            }
+            for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)acc_row(ta, r) * ld + acc_col(tb)];
+    gemm_tile_128<true, true>(Pi, ld, Pj, ld, 0, klen, acc, lds);
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = -acc[ta][tb][r];
 }
 
 // Zero the strict upper triangle (the factorisation leaves stale values there).
