@@ -467,7 +467,7 @@ int launch_trsv_vec(gpbo_ctx* ctx, const double* L, const double* src, double* d
     const size_t vbytes = (size_t)ctx->n_pad * S * sizeof(double);
     HIPCHK(hipMemcpyAsync(ctx->work, src, vbytes, hipMemcpyDeviceToDevice, ctx->stream));
     for (int p = 0; p < nb; ++p)
-        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nb - p, 1, S), dim3(256), 0, ctx->stream, L, ld, (const double*)ctx->Dinv, ctx->work,
+        hipLaunchKernelGGL(k_trsv_fwd_step, dim3(nb - p, 1, S), dim3(TRSV_FWD_THREADS), 0, ctx->stream, L, ld, (const double*)ctx->Dinv, ctx->work,
                            ctx->zv, p, ctx->bs, gate);
     if (keep_z) HIPCHK(hipMemcpyAsync(ctx->zfw, ctx->zv, vbytes, hipMemcpyDeviceToDevice, ctx->stream));   // z = L^-1 y
     for (int p = nb - 1; p >= 0; --p)

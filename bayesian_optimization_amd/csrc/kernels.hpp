@@ -542,8 +542,14 @@ __device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __
         __syncthreads();
         GPBO_STAMP(2, 1);
         // trailing triangle: A[I, J] -= X_I X_J^T over the tile pairs I >= J; pair 0 is the next diagonal tile
+        // With more than four waves, those that share wave 0's SIMD (w = 4, 8, ...) sit this phase out: the tile
+        // factorisation is a chain of dependent instructions and runs faster with its SIMD to itself.
         const int npair = nt * (nt + 1) / 2;
-        const int first = (w == 0) ? 0 : w, step = (nw > 1) ? nw - 1 : 1;
+        const bool spare = nw > 4;
+        const int helpers = spare ? nw - nw / 4 : nw - 1;                // waves working on pairs 1 ..
+        const int hidx = spare ? w - 1 - w / 4 : w - 1;                  // this wave's index among them
+        const bool idle = spare && w != 0 && (w & 3) == 0;
+        const int first = (w == 0) ? 0 : (idle ? npair : 1 + hidx), step = helpers > 0 ? helpers : 1;
         for (int pr = first; pr < npair; pr = (pr == 0 && nw > 1) ? npair : pr + step) {
             int ti, tj;
             tri_decode(pr, ti, tj);
@@ -928,10 +934,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
             for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = -acc[ta][tb][r];
 }
 
+// Sums of N (a power of two, <= 32) per-lane values over the 64 lanes of a wave: on return every lane holds the total of
+// value lane / (64 / N).  Each exchange halves the number of values a lane carries (the half it gives up travels to the
+// partner lane): N - 1 exchanges plus a butterfly on the one value left, instead of N butterflies of six exchanges, and
+// none of them waits for another value's turn.  The pairing tree (partners at distance 32, 16, 8, 4, 2, 1) and
+// therefore every rounding is that of   for (o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o)   applied to each value.
+template <int N>
+__device__ __forceinline__ double wave_sum(double (&s)[N]) {
+    const int lane = threadIdx.x & 63;
+    int dist = 32;
+#pragma unroll
+    for (int h = N / 2; h >= 1; h >>= 1, dist >>= 1) {
+        const bool up = (lane & dist) != 0;
+#pragma unroll
+        for (int u = 0; u < h; ++u) {
+            const double keep = up ? s[u + h] : s[u];
+            const double give = up ? s[u] : s[u + h];
+            s[u] = keep + __shfl_xor(give, dist);
+        }
+    }
+    double r = s[0];
+#pragma unroll
+    for (; dist >= 1; dist >>= 1) r += __shfl_xor(r, dist);
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------
 // Triangular solves for one right-hand side, one launch per 128-block step.
 // Forward step p: z_p = inv(L_pp) w_p ; w_ib -= L[ib,p] z_p for ib > p.   grid = nb - p.
-__global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict__ L, long ld,
+constexpr int TRSV_FWD_THREADS = 512;              // eight waves, 16 rows each: both operands fit the registers without spills
+__global__ __launch_bounds__(TRSV_FWD_THREADS) void k_trsv_fwd_step(const double* __restrict__ L, long ld,
                                                        const double* __restrict__ Dinv, double* __restrict__ w,
                                                        double* __restrict__ z, int p, BatchStride bs,
                                                        const double* __restrict__ gate) {
@@ -943,44 +975,45 @@ __global__ __launch_bounds__(256) void k_trsv_fwd_step(const double* __restrict_
     z += blockIdx.z * bs.vec;
     __shared__ double zp[PB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < PB) yp[tid] = w[p * PB + tid];
-    __syncthreads();
+    // Both operands of the step (this wave's 16 rows of the inverted diagonal block and of the block of L below) are
+    // requested before anything is waited for: the step is a chain of memory round trips and little else, and this
+    // makes it one round trip instead of eight.  Row of value u: wv + 8 u.
     const double* dinv = Dinv + (long)p * PB * PB;
-    const double y0 = yp[lane], y1 = yp[64 + lane];
-    for (int r0 = wv; r0 < PB; r0 += 32) {          // eight rows per batch: their loads are in flight together
-        double s[8];
+    const int ib = p + blockIdx.x;
+    const double* Lp = L + (long)ib * PB * ld + (long)p * PB;
+    double d0[16], d1[16], l0[16], l1[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = r0 + 4 * u;
-            s[u] = dinv[r * PB + lane] * y0 + dinv[r * PB + 64 + lane] * y1;
-        }
+    for (int u = 0; u < 16; ++u) {
+        const int r = wv + 8 * u;
+        d0[u] = dinv[r * PB + lane];
+        d1[u] = dinv[r * PB + 64 + lane];
+    }
+    if (blockIdx.x != 0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
-            if (lane == 0) zp[r0 + 4 * u] = s[u];
+        for (int u = 0; u < 16; ++u) {
+            const int r = wv + 8 * u;
+            l0[u] = Lp[(long)r * ld + lane];
+            l1[u] = Lp[(long)r * ld + 64 + lane];
         }
     }
+    if (tid < PB) yp[tid] = w[p * PB + tid];
+    __syncthreads();
+    const double y0 = yp[lane], y1 = yp[64 + lane];
+    double sv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sv[u] = d0[u] * y0 + d1[u] * y1;
+    const double zsum = wave_sum<16>(sv);           // value lane >> 2
+    if ((lane & 3) == 0) zp[wv + 8 * (lane >> 2)] = zsum;
     __syncthreads();
     if (blockIdx.x == 0) {
         if (tid < PB) z[p * PB + tid] = zp[tid];
         return;
     }
-    const int ib = p + blockIdx.x;
-    const double* Lp = L + (long)ib * PB * ld + (long)p * PB;
     const double z0 = zp[lane], z1 = zp[64 + lane];
-    for (int r0 = wv; r0 < PB; r0 += 32) {
-        double s[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = r0 + 4 * u;
-            s[u] = Lp[(long)r * ld + lane] * z0 + Lp[(long)r * ld + 64 + lane] * z1;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            for (int o = 32; o > 0; o >>= 1) s[u] += __shfl_xor(s[u], o);
-            if (lane == 0) w[ib * PB + r0 + 4 * u] -= s[u];
-        }
-    }
+    for (int u = 0; u < 16; ++u) sv[u] = l0[u] * z0 + l1[u] * z1;
+    const double wsum = wave_sum<16>(sv);
+    if ((lane & 3) == 0) w[ib * PB + wv + 8 * (lane >> 2)] -= wsum;
 }
 
 // Backward step p (L^T x = z): x_p = inv(L_pp)^T z_p ; z_jb -= L[p,jb]^T x_p for jb < p.  grid = p + 1.
@@ -997,14 +1030,24 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
     __shared__ double xp[PB];
     __shared__ double red[256];
     const int tid = threadIdx.x;
-    if (tid < PB) zp[tid] = z[p * PB + tid];
-    __syncthreads();
+    // as in the forward step: both operands are requested up front, one memory round trip per step
     const double* dinv = Dinv + (long)p * PB * PB;
     const int c = tid & 127, hh = tid >> 7;
+    const int jb = (int)blockIdx.x - 1;
+    const double* Lp = L + (long)p * PB * ld + (long)(jb < 0 ? 0 : jb) * PB;
+    double dv[64], lv[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) dv[u] = dinv[(hh * 64 + u) * PB + c];
+    if (blockIdx.x != 0) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) lv[u] = Lp[(long)(hh * 64 + u) * ld + c];
+    }
+    if (tid < PB) zp[tid] = z[p * PB + tid];
+    __syncthreads();
     {
         double s = 0.0;
-#pragma unroll 16
-        for (int r = hh * 64; r < hh * 64 + 64; ++r) s += dinv[r * PB + c] * zp[r];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) s += dv[u] * zp[hh * 64 + u];
         red[tid] = s;
     }
     __syncthreads();
@@ -1014,11 +1057,9 @@ __global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict_
         if (tid < PB) x[p * PB + tid] = xp[tid];
         return;
     }
-    const int jb = blockIdx.x - 1;
-    const double* Lp = L + (long)p * PB * ld + (long)jb * PB;
     double s = 0.0;
-#pragma unroll 16
-    for (int r = hh * 64; r < hh * 64 + 64; ++r) s += Lp[(long)r * ld + c] * xp[r];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) s += lv[u] * xp[hh * 64 + u];
     red[tid] = s;
     __syncthreads();
     if (tid < PB) z[jb * PB + tid] -= red[tid] + red[tid + 128];
