@@ -296,8 +296,8 @@ int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, doub
 }
 
 // Right-looking blocked Cholesky, panels of 128 columns processed in groups of CHOL_GROUP:
-// inside a group each panel is factored (diagonal block in one workgroup, panel solve by the inverted diagonal
-// block) and applied to the group's remaining block columns; after the group the whole trailing matrix is
+// inside a group each panel is factored (diagonal block in one workgroup, then the panel solve) and the group's own
+// block columns are brought up to date recursively (chol_factor_group); after the group the whole trailing matrix is
 // updated once with K = 128*group.
 int chol_group(int nb) {
     if (const char* e = getenv("GPBO_CHOL_GROUP")) return std::max(1, atoi(e));
@@ -321,29 +321,33 @@ int chol_first_deferred(int nb) {
 }
 
 // F(group): the latency-bound part.  Needs the group's block columns up to date.
+// Inside the group the panels are applied to the group's own block columns recursively: factor the left half, update
+// the right half's columns with the whole left half at once (K = 128 * half), factor the right half.  The number of
+// launches on the critical path is that of one K = 128 update per panel, but a tile of the group's columns is read and
+// written log2(g) times instead of up to g - 1 times, and most of the flops run at K = 256 and up.
 void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, int p0, int g) {
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
     static const int potrf_threads = getenv("GPBO_POTRF_THREADS") ? atoi(getenv("GPBO_POTRF_THREADS")) : POTRF_MFMA_THREADS;
-    const int first_deferred = chol_first_deferred(nb);
-    for (int q = p0; q < p0 + g; ++q) {
-        const unsigned S = (unsigned)ctx->batch;
-        const int defer = q >= first_deferred;
-        if (chol_potrf_valu())
-            hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, 0);
+    const unsigned S = (unsigned)ctx->batch;
+    if (g > 1) {
+        const int h = g / 2, c0 = p0 + h;          // columns c0 .. p0 + g - 1 take panels p0 .. c0 - 1
+        chol_factor_group(st, ctx, A, info_dev, p0, h);
+        hipLaunchKernelGGL(k_syrk_update<false>, dim3(g - h, nb - c0, S), dim3(GEMM_THREADS), 0, st, A, ld, c0, c0, p0 * PB, h * PB, ctx->bs);
+        chol_factor_group(st, ctx, A, info_dev, c0, g - h);
+        return;
+    }
+    const int q = p0;
+    const int defer = q >= chol_first_deferred(nb);
+    if (chol_potrf_valu())
+        hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, 0);
+    else
+        hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1, 1, S), dim3(potrf_threads), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, defer);
+    if (q + 1 < nb) {
+        if (defer)
+            hipLaunchKernelGGL(k_trsm_rows, dim3(8 * (nb - q - 1), 1, S), dim3(64), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
         else
-            hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1, 1, S), dim3(potrf_threads), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs,
-                               defer);
-        if (q + 1 < nb) {
-            if (defer)
-                hipLaunchKernelGGL(k_trsm_rows, dim3(8 * (nb - q - 1), 1, S), dim3(64), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
-            else
-                hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1, 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
-        }
-        const int rest = p0 + g - 1 - q;      // the group's block columns right of q take panel q at once (K = 128):
-        if (rest > 0)                         // more tiles per launch and a shorter chain than one growing-K update per column
-            hipLaunchKernelGGL(k_syrk_update<false>, dim3(rest, nb - q - 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q + 1, q + 1, q * PB, PB,
-                               ctx->bs);
+            hipLaunchKernelGGL(k_trsm_panel, dim3(nb - q - 1, 1, S), dim3(GEMM_THREADS), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
     }
 }
 
@@ -443,9 +447,10 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
             const int g = std::min(G, nb - p0);
             chol_factor_group(ctx->stream, ctx, A, info_dev, p0, g);
             const int T = nb - (p0 + g);
-            if (T > 0)
+            if (T > 0) {
                 hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
                                    ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
+            }
         }
     }
     const int first_deferred = chol_first_deferred(nb);
