@@ -72,6 +72,49 @@ template <int VAR> __global__ __launch_bounds__(1024) void k_leaf(const double* 
     out[lane] = s;
     if (lane == 0) { cyc[0] = t1 - t0; cyc[1] = wall_clock64() - w0; }
 }
+
+// 32x32 tile: lanes 0..31 rows of A, lanes 32..63 rows of the identity
+__global__ __launch_bounds__(1024) void k_leaf32(const double* __restrict__ A, double* __restrict__ out, long long* __restrict__ cyc) {
+    const int lane = threadIdx.x & 63, i = lane;
+    double v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = (i < 32) ? ((c <= i) ? A[(i & 31) * 32 + c] : 0.0) : ((c == i - 32) ? 1.0 : 0.0);
+    double v0[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v0[c] = v[c];
+    long long t0, t1;
+    const long long w0 = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) : : "memory");
+  for (int rep = 0; rep < 64; ++rep) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) asm volatile("" : "+v"(v[c]));
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const double piv = readlane_f64(v[j], j);
+        double rd = __builtin_amdgcn_rsq(piv);
+        rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
+        rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
+        double d = piv * rd;
+        d = fma(0.5 * rd, fma(-d, d, piv), d);
+        const double lij = (i > j) ? v[j] * rd : 0.0;
+        v[j] = (i == j) ? d : lij;
+#pragma unroll
+        for (int c = j + 1; c < 32; ++c) {
+            const double lcj = readlane_f64(v[j], c);
+            v[c] = fma(-lij, lcj, v[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { v[c] = fma(1e-9, v[c], v0[c]); asm volatile("" : "+v"(v[c])); }
+  }
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s += v[c];
+    asm volatile("s_nop 0\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(s) : "memory");
+    out[lane] = s;
+    if (lane == 0) { cyc[0] = t1 - t0; cyc[1] = wall_clock64() - w0; }
+}
+
 template <int VAR> void run(const double* dA, double* dout, long long* dcyc) {
     long long best = 1ll << 60, wall = 0;
     for (int rep = 0; rep < 5; ++rep) {
@@ -90,5 +133,18 @@ int main() {
     (void)hipMalloc(&dA, 256 * 8); (void)hipMalloc(&dout, 64 * 8); (void)hipMalloc(&dcyc, 16);
     (void)hipMemcpy(dA, A.data(), 256 * 8, hipMemcpyHostToDevice);
     run<0>(dA, dout, dcyc); run<1>(dA, dout, dcyc); run<2>(dA, dout, dcyc); run<3>(dA, dout, dcyc); run<4>(dA, dout, dcyc); run<5>(dA, dout, dcyc); run<6>(dA, dout, dcyc); run<7>(dA, dout, dcyc);
+    {
+        std::vector<double> B(1024);
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j) B[i * 32 + j] = exp(-0.5 * (i - j) * (i - j) / 9.0) + (i == j ? 0.1 : 0.0);
+        double* dB; (void)hipMalloc(&dB, 1024 * 8);
+        (void)hipMemcpy(dB, B.data(), 1024 * 8, hipMemcpyHostToDevice);
+        for (int rep = 0; rep < 3; ++rep) {
+            k_leaf32<<<1, 64>>>(dB, dout, dcyc);
+            long long c[2];
+            (void)hipMemcpy(c, dcyc, 16, hipMemcpyDeviceToHost);
+            printf("32x32 tile: %lld ticks, %.2f us per tile\n", c[0] / 64, c[1] / 100.0 / 64);
+        }
+    }
     return 0;
 }
