@@ -309,15 +309,15 @@ int chol_group(int nb) {
 // SIMDs); beyond that the 128-tile engine, which shares the inverted block through LDS, is faster (measured at
 // n = 32768).  The row form needs only the inverses of the 16x16 diagonal tiles, so for those panels the diagonal-block
 // kernel stops after the factor ("deferred") and k_trinv_diag forms the block inverses after the factorisation, all in
-// one launch, off the critical path.  Panels from chol_first_deferred(nb) on are deferred.
+// one launch, off the critical path.  Panels from chol_first_deferred(nb, slots) on are deferred.
 bool chol_potrf_valu() {
     static const bool v = getenv("GPBO_POTRF_VALU") && atoi(getenv("GPBO_POTRF_VALU")) != 0;
     return v;
 }
-int chol_first_deferred(int nb) {
+int chol_first_deferred(int nb, int batch) {
     static const int trsm_rows_max = getenv("GPBO_TRSM_ROWS_MAX") ? atoi(getenv("GPBO_TRSM_ROWS_MAX")) : 128;
     if (chol_potrf_valu()) return nb;              // the all-VALU diagonal kernel (comparison runs) always inverts in place
-    return std::max(0, nb - 1 - trsm_rows_max);
+    return std::max(0, nb - 1 - trsm_rows_max / std::max(1, batch));      // block rows below the panel, over all slots
 }
 
 // F(group): the latency-bound part.  Needs the group's block columns up to date.
@@ -338,7 +338,7 @@ void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, 
         return;
     }
     const int q = p0;
-    const int defer = q >= chol_first_deferred(nb);
+    const int defer = q >= chol_first_deferred(nb, ctx->batch);
     if (chol_potrf_valu())
         hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, 0);
     else
@@ -453,7 +453,7 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
             }
         }
     }
-    const int first_deferred = chol_first_deferred(nb);
+    const int first_deferred = chol_first_deferred(nb, ctx->batch);
     if (first_deferred < nb)
         hipLaunchKernelGGL(k_trinv_diag, dim3((unsigned)(nb - first_deferred), 1, (unsigned)ctx->batch), dim3(1024), 0, ctx->stream,
                            (const double*)A, ld, first_deferred, ctx->Dinv, ctx->bs);
