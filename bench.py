@@ -13,8 +13,10 @@ A step = one full pass over this rank's resident candidate block: K(X*,X) tiles,
 The model is fitted once (rank 0) and broadcast before the timed region; candidates are resident in HBM.
 value = candidates processed by all ranks / max-over-ranks time.  Rank 0 prints one JSON line.
 
-The default line measures BASELINE.json's 4096-point configuration (cfg2) and carries a second block, "cfg3", with the
-32768-point Matern-5/2 model of the 64 M-candidate configuration on a bounded slice of its candidates.
+The default line measures BASELINE.json's 4096-point configuration (cfg2) and carries three more blocks: "cfg3", the
+32768-point Matern-5/2 model of the 64 M-candidate configuration on a bounded slice of its candidates; "cfg4", 200 EI
+iterations with incremental updates on the 64^4 candidate lattice; "cfg5", 32 likelihood settings per GPU at n = 16384
+(--no-cfg3 / --no-cfg45 leave them out).
 """
 import argparse
 import json
@@ -248,17 +250,15 @@ def sweep_block(a, config, gp, world, rank, backend, steps, warmup, with_cpu):
     return out
 
 
-def secondary(a):
-    """The two other GPU configurations of BASELINE.json, same launch contract and JSON shape.
-    cfg4: BayesOpt_v4-style loop, theta frozen: EI iterations with incremental append on a 64^4 candidate lattice
-          (a step = one iteration: acquisition + argmax + border-append + the HBM-streaming sweep of the resident V).
-    cfg5: 256 (length-scale, noise) settings of -logL + analytic gradient at n = 16384 (a step = the whole sweep of this
-          rank's share of the settings; ranks take disjoint settings, no exchange)."""
+def cfg4_block(a, gp, world, rank, backend, iters, warmup):
+    """cfg4: BayesOpt_v4-style loop, theta frozen: EI iterations with incremental append on a 64^4 candidate lattice
+    (a step = one iteration: acquisition + argmax + border-append + the HBM-streaming sweep of the resident V).
+    Returns the JSON dictionary on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
     import bayesian_optimization_amd as bo
-    from bayesian_optimization_amd import GP, synth
-    world, rank, local_rank, backend = _dist_setup()
+    from bayesian_optimization_amd import synth
+    from bayesian_optimization_amd import dist as gdist
 
     def barrier():
         torch.cuda.synchronize()
@@ -266,95 +266,116 @@ def secondary(a):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def maxtime(dt):
-        return _max_over_ranks(dt, world, backend)
+    d, side, n0 = 4, a.side, 16
+    g1 = (np.arange(side) + 0.5) / side
+    m_total = side ** d
+    sharded = world > 1 and not a.replicas       # candidate rows (and the resident V) split over the ranks: one loop, strong scaling
+    lo, hi = gdist.shard_range(m_total, rank, world) if sharded else (0, m_total)
+    # lexicographic order, as the notebooks' nested loops; built per block from the flat index
+    ii = np.arange(lo, hi)
+    grid = np.stack([g1[(ii // side ** (d - 1 - k)) % side] for k in range(d)], -1)
+    f = lambda x: np.exp(-8 * np.sum((x - 0.37) ** 2, -1)) + 0.5 * np.exp(-20 * np.sum((x - 0.8) ** 2, -1))
+    X0 = synth.uniform(4 if sharded else 4 + rank, n0 * d).reshape(n0, d)     # replicas: every rank runs its own independent loop
+    gp.reserve_appends(iters + warmup)
+    gp.fit(X0, f(X0), np.full(d, 0.25), 1e-2, variant=bo.VARIANT_SINGLE)
+    loop = gdist.ShardedLoop(gp, grid, lo)
+    m = len(grid)
+    sweep_ms, bytes_alg = 0.0, 0.0
+    picked = []
+    # an iteration = append the point picked last + sweep + pick the next one (ShardedLoop.step)
+    jj, _, x = loop.propose(bo.ACQ_EI, 0.01)
+    for it in range(warmup):
+        picked.append(jj)
+        jj, _, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(iters):
+        picked.append(jj)
+        n_before = gp.n
+        jj, ei, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
+        tm = gp.timings()
+        sweep_ms += tm['append_sweep_ms']
+        bytes_alg += m * (8.0 * n_before + 8 + 32 + 8 * d)     # V read + new V row + (mu, var r/w; sum v^2 r/w) + candidates
+    barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, world, backend)
+    if rank != 0:
+        return None
+    achieved = bytes_alg / (sweep_ms * 1e-3) / 1e9
+    loops = 1 if sharded else world
+    return {
+        'metric': 'bo_loop_iterations_per_sec', 'value': loops * iters / dt, 'unit': 'iterations/s', 'n_gpus': world,
+        'ranks_seen': _ranks_seen(world),
+        'steps': iters, 'warmup': warmup, 'ms_per_step': dt / iters * 1e3, 'higher_is_better': True,
+        'scaling': 'strong' if sharded else 'weak',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'cfg4: %d EI iterations, incremental append (theta frozen, single-factor posterior), '
+                               '%d^4 = %d candidate lattice, d=4, n0=%d, sigmaY=1e-2; %s'
+                               % (iters, side, m_total, n0, 'candidate rows and resident V split over the GPUs, one loop'
+                                  if sharded else 'one independent loop per GPU'),
+                   'n_final': gp.n, 'best_y': float(gp.y_max), 'picked_head': [int(j) for j in picked[:16]]},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_append_sweep', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': sweep_ms / iters,
+                     'bytes_per_launch_avg': bytes_alg / iters}}
 
+
+def cfg5_block(a, gp, world, rank, backend, per, steps, warmup):
+    """cfg5: (length-scale, noise) settings of -logL + analytic gradient at n = 16384, `per` of the 256 per GPU (a step =
+    the whole sweep of this rank's share; ranks take disjoint settings, no exchange).  Rank 0 returns the dictionary."""
+    import torch
+    import torch.distributed as dist
+    from bayesian_optimization_amd import synth
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n, d = (a.n or 16384), 8
+    Btot = 256
+    X = synth.uniform(5, n * d).reshape(n, d)
+    y = np.sin(3 * X.sum(1)) + 0.1 * synth.normal(105, n)
+    mult = np.geomspace(0.25, 2.0, 16)
+    sigs = np.geomspace(1e-2, 1.0, 16)
+    allset = [(mm, ss) for mm in mult for ss in sigs]
+    mine = [allset[(rank * per + i) % Btot] for i in range(per)]
+    thetas = np.array([np.full(d, 0.5 * mm) for mm, _ in mine])
+    sig = np.array([ss for _, ss in mine])
+    for _ in range(warmup):
+        gp.lml_batch(X, y, thetas[:2], sig[:2], grad=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nll, grad, stat = gp.lml_batch(X, y, thetas, sig, grad=True)
+    barrier()
+    dt = _max_over_ranks(time.perf_counter() - t0, world, backend)
+    if rank != 0:
+        return None
+    flops = float(n) ** 3 * per * steps * world       # n^3/3 Cholesky + n^3/3 inverse + n^3/3 W^T W per setting
+    achieved = flops / dt / 1e12 / world
+    return {
+        'metric': 'lml_grad_settings_per_sec', 'value': world * per * steps / dt, 'unit': 'settings/s', 'n_gpus': world,
+        'ranks_seen': _ranks_seen(world),
+        'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'cfg5: -logL + analytic gradient, n=%d, d=%d, RBF, %d settings per GPU (16 length-scale multipliers x 16 sigmaY)' % (n, d, per),
+                   'failed_settings': int(np.sum(stat != 0))},
+        'roofline': {'bound': 'mfma', 'kernel': 'whole sweep (Cholesky + inverse + W^T W tiles)', 'achieved': achieved,
+                     'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None}}
+
+
+def secondary(a):
+    """The two other GPU configurations of BASELINE.json on their own, same launch contract and JSON shape."""
+    import torch.distributed as dist
+    from bayesian_optimization_amd import GP
+    world, rank, local_rank, backend = _dist_setup()
     gp = GP(local_rank)
     if a.config == 'cfg4':
-        from bayesian_optimization_amd import dist as gdist
-        d, side, n0 = 4, a.side, 16
-        g1 = (np.arange(side) + 0.5) / side
-        m_total = side ** d
-        sharded = world > 1 and not a.replicas       # candidate rows (and the resident V) split over the ranks: one loop, strong scaling
-        lo, hi = gdist.shard_range(m_total, rank, world) if sharded else (0, m_total)
-        # lexicographic order, as the notebooks' nested loops; built per block from the flat index
-        ii = np.arange(lo, hi)
-        grid = np.stack([g1[(ii // side ** (d - 1 - k)) % side] for k in range(d)], -1)
-        f = lambda x: np.exp(-8 * np.sum((x - 0.37) ** 2, -1)) + 0.5 * np.exp(-20 * np.sum((x - 0.8) ** 2, -1))
-        X0 = synth.uniform(4 if sharded else 4 + rank, n0 * d).reshape(n0, d)     # replicas: every rank runs its own independent loop
-        iters = a.iters
-        gp.reserve_appends(iters + a.warmup)
-        gp.fit(X0, f(X0), np.full(d, 0.25), 1e-2, variant=bo.VARIANT_SINGLE)
-        loop = gdist.ShardedLoop(gp, grid, lo)
-        m = len(grid)
-        sweep_ms, bytes_alg = 0.0, 0.0
-        picked = []
-        # an iteration = append the point picked last + sweep + pick the next one (ShardedLoop.step)
-        jj, _, x = loop.propose(bo.ACQ_EI, 0.01)
-        for it in range(a.warmup):
-            picked.append(jj)
-            jj, _, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
-        barrier()
-        t0 = time.perf_counter()
-        for it in range(iters):
-            picked.append(jj)
-            n_before = gp.n
-            jj, ei, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
-            tm = gp.timings()
-            sweep_ms += tm['append_sweep_ms']
-            bytes_alg += m * (8.0 * n_before + 8 + 32 + 8 * d)     # V read + new V row + (mu, var r/w; sum v^2 r/w) + candidates
-        barrier()
-        dt = maxtime(time.perf_counter() - t0)
-        if rank == 0:
-            achieved = bytes_alg / (sweep_ms * 1e-3) / 1e9
-            loops = 1 if sharded else world
-            print(json.dumps({
-                'metric': 'bo_loop_iterations_per_sec', 'value': loops * iters / dt, 'unit': 'iterations/s', 'n_gpus': world,
-                'ranks_seen': _ranks_seen(world),
-                'steps': iters, 'warmup': a.warmup, 'ms_per_step': dt / iters * 1e3, 'higher_is_better': True,
-                'scaling': 'strong' if sharded else 'weak',
-                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-                'config': {'workload': 'cfg4: %d EI iterations, incremental append (theta frozen, single-factor posterior), '
-                                       '%d^4 = %d candidate lattice, d=4, n0=%d, sigmaY=1e-2; %s'
-                                       % (iters, side, m_total, n0, 'candidate rows and resident V split over the GPUs, one loop'
-                                          if sharded else 'one independent loop per GPU'),
-                           'n_final': gp.n, 'best_y': float(gp.y_max), 'picked_head': [int(j) for j in picked[:16]]},
-                'roofline': {'bound': 'hbm', 'kernel': 'k_append_sweep', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': sweep_ms / iters,
-                             'bytes_per_launch_avg': bytes_alg / iters}}), flush=True)
+        out = cfg4_block(a, gp, world, rank, backend, a.iters, a.warmup)
     else:
-        n, d = (a.n or 16384), 8
-        Btot = 256
-        per = a.settings if a.settings else max(1, Btot // world)
-        X = synth.uniform(5, n * d).reshape(n, d)
-        y = np.sin(3 * X.sum(1)) + 0.1 * synth.normal(105, n)
-        mult = np.geomspace(0.25, 2.0, 16)
-        sigs = np.geomspace(1e-2, 1.0, 16)
-        allset = [(mm, ss) for mm in mult for ss in sigs]
-        mine = [allset[(rank * per + i) % Btot] for i in range(per)]
-        thetas = np.array([np.full(d, 0.5 * mm) for mm, _ in mine])
-        sig = np.array([ss for _, ss in mine])
-        for _ in range(a.warmup):
-            gp.lml_batch(X, y, thetas[:2], sig[:2], grad=True)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            nll, grad, stat = gp.lml_batch(X, y, thetas, sig, grad=True)
-        barrier()
-        dt = maxtime(time.perf_counter() - t0)
-        if rank == 0:
-            flops = float(n) ** 3 * per * a.steps * world       # n^3/3 Cholesky + n^3/3 inverse + n^3/3 W^T W per setting
-            achieved = flops / dt / 1e12 / world
-            print(json.dumps({
-                'metric': 'lml_grad_settings_per_sec', 'value': world * per * a.steps / dt, 'unit': 'settings/s', 'n_gpus': world,
-                'ranks_seen': _ranks_seen(world),
-                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-                'config': {'workload': 'cfg5: -logL + analytic gradient, n=%d, d=%d, RBF, %d settings per GPU (16 length-scale multipliers x 16 sigmaY)' % (n, d, per),
-                           'failed_settings': int(np.sum(stat != 0))},
-                'roofline': {'bound': 'mfma', 'kernel': 'whole sweep (Cholesky + inverse + W^T W tiles)', 'achieved': achieved,
-                             'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None}}),
-                flush=True)
+        out = cfg5_block(a, gp, world, rank, backend, a.settings if a.settings else max(1, 256 // world), a.steps, a.warmup)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     gp.close()
     if world > 1:
         dist.destroy_process_group()
@@ -394,6 +415,7 @@ def main():
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cfg3', action='store_true', help='leave the 32768-point block out of the default line')
+    ap.add_argument('--no-cfg45', action='store_true', help='leave the lattice-loop and likelihood-sweep blocks out of the default line')
     ap.add_argument('--iters', type=int, default=200, help='cfg4: EI iterations')
     ap.add_argument('--side', type=int, default=64, help='cfg4: points per axis of the candidate lattice')
     ap.add_argument('--replicas', action='store_true', help='cfg4 with several GPUs: independent loops instead of one sharded loop')
@@ -429,9 +451,23 @@ def main():
         if rank == 0:
             out['cfg3'] = {k: blk[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'config', 'roofline',
                                                'phases_ms_per_step', 'phase_rooflines', 'fit', 'end_to_end', 'argmax')}
+    gp.close()
+    if a.config == 'cfg2' and not a.no_cfg45 and not a.n and not a.m:
+        # the two remaining GPU configurations, each in a context of its own: the 64^4-lattice loop (200 iterations) and 32
+        # likelihood settings per GPU at n = 16384
+        keys = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'config', 'roofline')
+        gp4 = GP(local_rank)
+        blk = cfg4_block(a, gp4, world, rank, backend, 200, 1)
+        gp4.close()
+        if rank == 0:
+            out['cfg4'] = {k: blk[k] for k in keys}
+        gp5 = GP(local_rank)
+        blk = cfg5_block(a, gp5, world, rank, backend, 32, 1, 1)
+        gp5.close()
+        if rank == 0:
+            out['cfg5'] = {k: blk[k] for k in keys}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    gp.close()
     if world > 1:
         dist.destroy_process_group()
 

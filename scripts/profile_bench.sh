@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel-trace statistics (and, with PMC=1, the three counter passes) of one bench.py workload; run on the GPU box from
-# the repository root:   scripts/profile_bench.sh <tag> [bench.py arguments]
+# the repository root:   scripts/profile_bench.sh <tag> [bench.py arguments]   (cfg2 alone: --no-cfg3 --no-cfg45)
 # Summaries land in gpurun_out/prof_<tag>/ (copy what is to be kept into profiles/).
 set -o pipefail
 cd "$(dirname "$0")/.." || exit 1
