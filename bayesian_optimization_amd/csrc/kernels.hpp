@@ -939,23 +939,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
 // partner lane): N - 1 exchanges plus a butterfly on the one value left, instead of N butterflies of six exchanges, and
 // none of them waits for another value's turn.  The pairing tree (partners at distance 32, 16, 8, 4, 2, 1) and
 // therefore every rounding is that of   for (o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o)   applied to each value.
+template <int N, int H>
+__device__ __forceinline__ void wave_sum_level(double (&s)[N], int lane) {
+    // H values stay, partner distance 64 H / N; compile-time recursion keeps every index of s a constant (a loop over
+    // the levels is not unrolled by the compiler, and s then turns into chains of selects)
+    constexpr int dist = 64 * H / N;
+    const bool up = (lane & dist) != 0;
+    double give[H];
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+        give[u] = up ? s[u] : s[u + H];
+        s[u] = up ? s[u + H] : s[u];
+    }
+#pragma unroll
+    for (int u = 0; u < H; ++u) give[u] = __shfl_xor(give[u], dist);     // all of a level's exchanges are in flight together
+#pragma unroll
+    for (int u = 0; u < H; ++u) s[u] += give[u];
+    if constexpr (H > 1) wave_sum_level<N, H / 2>(s, lane);
+}
 template <int N>
 __device__ __forceinline__ double wave_sum(double (&s)[N]) {
+    static_assert(N >= 2 && N <= 32 && (N & (N - 1)) == 0, "a power of two between 2 and 32");
     const int lane = threadIdx.x & 63;
-    int dist = 32;
-#pragma unroll
-    for (int h = N / 2; h >= 1; h >>= 1, dist >>= 1) {
-        const bool up = (lane & dist) != 0;
-#pragma unroll
-        for (int u = 0; u < h; ++u) {
-            const double keep = up ? s[u + h] : s[u];
-            const double give = up ? s[u] : s[u + h];
-            s[u] = keep + __shfl_xor(give, dist);
-        }
-    }
+    wave_sum_level<N, N / 2>(s, lane);
     double r = s[0];
 #pragma unroll
-    for (; dist >= 1; dist >>= 1) r += __shfl_xor(r, dist);
+    for (int dist = 32 / N; dist >= 1; dist >>= 1) r += __shfl_xor(r, dist);
     return r;
 }
 
