@@ -36,6 +36,16 @@ constexpr int MAX_D = 32;
 // instead of a square grid whose upper half exits at once is worth 10-35 % on the triangular updates: an empty
 // workgroup still occupies a dispatch slot and its 72 KiB of LDS for a moment.
 __device__ __forceinline__ void tri_decode(int t, int& i, int& j) {
+    if (t < (1 << 22)) {
+        // single precision puts the root within one of i here (one instruction instead of the ~40 of a double square
+        // root: this sits at the head of every triangular-grid workgroup and inside the diagonal-block kernel's phases);
+        // the two loops make it exact
+        i = (int)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        while (i * (i + 1) / 2 > t) --i;
+        j = t - i * (i + 1) / 2;
+        return;
+    }
     i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((long)(i + 1) * (i + 2) / 2 <= t) ++i;
     while ((long)i * (i + 1) / 2 > t) --i;
@@ -461,7 +471,10 @@ constexpr int LEAF_DOUBLES = 16 * LEAF_P;
 // i.e. column m of the inverse, from the very instructions that factor A.  Lanes >= 32 idle along.
 __device__ __forceinline__ int leaf_potrf_inv(double* __restrict__ M, int c0, double* __restrict__ Wi) {
     const int lane = threadIdx.x & 63;
-    const int i = lane & 31;                       // row of [A; I]
+    int i = lane & 31;                             // row of [A; I]
+    // opaque per call: otherwise the 32 lane masks (i > j, i == j) are hoisted out of the caller's loop over the tiles,
+    // do not fit the scalar registers and come back through v_readlane from a spill register inside the pivot chain
+    asm volatile("" : "+v"(i));
     double v[16];
     {
         // all sixteen reads are issued before the first is used (every lane reads a valid address; the empty asm keeps
