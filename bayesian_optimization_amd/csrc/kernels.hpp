@@ -112,13 +112,12 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
 // ---------------------------------------------------------------------------------------
 
 // Diagonal block p of the blocked factorisation: Cholesky factor of the 128x128 block and its inverse in one
-// workgroup of 256 threads, both on a packed copy of the lower triangle in LDS (potrf128_lds: eight 16-column panels;
-// trinv128_lds: recursive doubling).  0.14 ms per block; a column-by-column elimination of the whole block on
-// register tiles (256 barriers) took 0.19 ms, a reduction form 0.38 ms.
+// workgroup, both on a packed copy of the lower triangle in LDS.  Two forms: all-VALU, 256 threads (potrf128_lds: eight
+// 16-column panels; trinv128_lds: recursive doubling; 0.12 ms per block, kept for same-machine comparison) and the MFMA
+// form further down (potrf128_mfma / trinv128_mfma, 1024 threads, 0.034 ms), which the one-workgroup likelihood kernel
+// uses as well.  A column-by-column elimination of the whole block on register tiles (256 barriers) took 0.19 ms.
 // Writes L (lower, zeros above) back into A and inv(L) (lower, zeros above) into Dinv.
 // info: first failing 1-based global row (pivot <= 0 or NaN), set once.
-// The register-tile elimination (potrf_factor_regs / potrf_inverse_regs) is kept for the one-workgroup likelihood
-// kernel, whose covariance tiles are born in registers.
 constexpr int POTRF_THREADS = 256;
 // The inverse phase reads L from a packed lower-triangular LDS copy (row r starts at r (r + 1) / 2); a wave reads four
 // distinct addresses per access (one per tile row): broadcasts, no bank conflicts.  The LDS request is padded to
@@ -126,112 +125,6 @@ constexpr int POTRF_THREADS = 256;
 // fit on a CU that holds a tile-engine workgroup (72 KB of 160).
 __device__ __forceinline__ constexpr int tri_off(int r) { return r * (r + 1) / 2; }
 constexpr int POTRF_LDS_PACKED = PB * (PB + 1) / 2;     // 8256 doubles
-// Factor phase on register tiles.  vec: [2][PB] LDS, dg: [PB] LDS (receives diag L).  Returns the first failing
-// column (pivot <= 0 or NaN) or -1.  All 256 threads must call it; it ends without a barrier after the last step.
-// nt: number of leading 8-column tile columns to eliminate; the rest of the block must be the identity pad (rows and
-// columns >= 8 nt zero off the diagonal, one on it), which elimination leaves as it is.
-__device__ __forceinline__ int potrf_factor_regs(double (&a)[8][8], double* __restrict__ vec, double* __restrict__ dg,
-                                                 int nt = 16) {
-    const int tid = threadIdx.x;
-    const int tr = tid >> 4, tc = tid & 15;
-    const bool lower = tr >= tc;
-    int fail = -1;
-    if (tid < PB && tid >= nt * 8) dg[tid] = 1.0;      // beyond nt tile columns the block is the identity pad
-    for (int jt = 0; jt < nt; ++jt) {
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int j = jt * 8 + jj;
-            double* buf = vec + (j & 1) * PB;
-            if (tc == jt && lower) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) buf[tr * 8 + rr] = a[rr][jj];
-            }
-            __syncthreads();
-            const double piv = buf[j];
-            if (!(piv > 0.0) && fail < 0) fail = j;
-            const double d = sqrt(piv);
-            const double rsq = 1.0 / d;
-            if (tc >= jt && lower) {
-                double lr[8], lc[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    lr[t] = buf[tr * 8 + t] * rsq;
-                    lc[t] = buf[tc * 8 + t] * rsq;
-                }
-                if (tc == jt) {
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) a[rr][jj] = lr[rr];          // final column j of L (rows > j)
-                    if (tr == jt) a[jj][jj] = d;
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-                        for (int cc = jj + 1; cc < 8; ++cc) a[rr][cc] = fma(-lr[rr], lc[cc], a[rr][cc]);
-                } else {
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = fma(-lr[rr], lc[cc], a[rr][cc]);
-                }
-            }
-            if (tid == 0) dg[j] = d;
-        }
-    }
-    return fail;
-}
-
-// Inverse phase: forward elimination on X = I held in the register tiles (a is overwritten), L read from the packed
-// LDS copy S, diag L from dg.  Step j: row j of X (scaled by 1/d_j) is final and published; rows r > j subtract
-// L[r][j] * X[j][:].  The caller has written S and dg and passed a barrier.
-__device__ __forceinline__ void potrf_inverse_regs(double (&a)[8][8], const double* __restrict__ S, double* __restrict__ vec,
-                                                   const double* __restrict__ dg, int nt = 16) {
-    const int tid = threadIdx.x;
-    const int tr = tid >> 4, tc = tid & 15;
-    const bool lower = tr >= tc;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = (tr == tc && rr == cc) ? 1.0 : 0.0;   // X = I
-    for (int jt = 0; jt < nt; ++jt) {
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int j = jt * 8 + jj;
-            double* buf = vec + (j & 1) * PB;
-            if (tr == jt && lower) {
-                const double rd = 1.0 / dg[j];
-#pragma unroll
-                for (int cc = 0; cc < 8; ++cc) {
-                    a[jj][cc] *= rd;
-                    buf[tc * 8 + cc] = a[jj][cc];
-                }
-            }
-            if (tr == jt && !lower) {          // columns right of the diagonal tile: X[j][c] = 0
-#pragma unroll
-                for (int cc = 0; cc < 8; ++cc) buf[tc * 8 + cc] = 0.0;
-            }
-            __syncthreads();
-            if (tr >= jt && lower) {
-                double xr[8], lcol[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    xr[t] = buf[tc * 8 + t];
-                    lcol[t] = S[tri_off(tr * 8 + t) + j];      // entries with row < j are read but never used
-                }
-                if (tr == jt) {
-#pragma unroll
-                    for (int rr = jj + 1; rr < 8; ++rr)
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = fma(-lcol[rr], xr[cc], a[rr][cc]);
-                } else {
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-                        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = fma(-lcol[rr], xr[cc], a[rr][cc]);
-                }
-            }
-        }
-    }
-}
-
 // Cholesky factor of the 128x128 block held packed in LDS (M, row r at tri_off(r)), in place, right-looking over eight
 // 16-column panels: (a) the 16x16 diagonal block by ONE wave (row i in lane i & 15, four columns per lane, the pivot
 // column exchanged through LDS; no workgroup barrier inside), (b) the rows below by substitution, one thread per row,
@@ -523,9 +416,16 @@ __device__ __forceinline__ int leaf_potrf_inv(double* __restrict__ M, int c0, do
 // updated.  The next diagonal tile is updated first, by wave 0, which goes on to factor it while the other waves
 // update the rest of the triangle: the tile factorisation (one wave, a chain of 16 pivots) is the critical path, and
 // this way only the small row-scaling phase stands between two of them.  All threads must call it; ends on a barrier.
-__device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __restrict__ Wi8, int* __restrict__ failp) {
+// ntl: number of leading 16x16 tile rows that hold data; from there on the block must be the identity pad (zero off the
+// diagonal, one on it), which is left as it is and whose tile inverses are set to the identity.
+__device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __restrict__ Wi8, int* __restrict__ failp,
+                                              int ntl = 8) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    for (int idx = tid; idx < (8 - ntl) * 256; idx += blockDim.x) {
+        const int b = ntl + (idx >> 8), r = (idx >> 4) & 15, c = idx & 15;
+        Wi8[b * LEAF_DOUBLES + r * LEAF_P + c] = (r == c) ? 1.0 : 0.0;
+    }
     auto leaf = [&](int jb) {
         const int fail = leaf_potrf_inv(M, 16 * jb, Wi8 + jb * LEAF_DOUBLES);
         if (lane == 0 && fail >= 0 && *failp < 0) *failp = fail;
@@ -534,10 +434,10 @@ __device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __
     if (w == 0) leaf(0);
     GPBO_STAMP(1, 1);
     __syncthreads();
-    for (int jb = 0; jb < 7; ++jb) {
+    for (int jb = 0; jb < ntl - 1; ++jb) {
         const int c0 = 16 * jb;
         const double* Wi = Wi8 + jb * LEAF_DOUBLES;
-        const int nt = 7 - jb;                       // 16-row tiles below the diagonal tile
+        const int nt = ntl - 1 - jb;                 // 16-row tiles below the diagonal tile (the pad has zeros there)
         GPBO_STAMP(0, 0);
         // rows below: X = A[rows, c0:c0+16] * inv(L11)^T, one tile per wave and turn
         for (int t = w; t < nt; t += nw) {
@@ -596,8 +496,9 @@ __device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __
 
 // One level of the block inverse on MFMA.  Before: the diagonal blocks of size S hold their inverses, the blocks below
 // them still hold L.  Pair p joins A = [2pS, 2pS+S) and B = A + S:  W[B,A] = -W[B,B] (L[B,A] W[A,A]).
+// ntl: tile rows from ntl on are the identity pad (see potrf128_mfma): their rows of W[B,A] are zero and stay untouched.
 template <int S>
-__device__ __forceinline__ void trinv_level_mfma(double* __restrict__ M, double* __restrict__ T) {
+__device__ __forceinline__ void trinv_level_mfma(double* __restrict__ M, double* __restrict__ T, int ntl) {
     constexpr int P = PB / (2 * S), NT = S / 16, TP = S + 1;
     constexpr int TILES = P * NT * NT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
@@ -605,6 +506,7 @@ __device__ __forceinline__ void trinv_level_mfma(double* __restrict__ M, double*
     for (int t = w; t < TILES; t += nw) {            // T = L[B,A] W[A,A]; W[A,A] lower: k-tiles kt >= jt
         const int p = t / (NT * NT), it = (t / NT) % NT, jt = t % NT;
         const int a0 = 2 * p * S, b0 = a0 + S;
+        if (b0 + 16 * it >= 16 * ntl) continue;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
         for (int kt = jt; kt < NT; ++kt) {
 #pragma unroll
@@ -622,6 +524,7 @@ __device__ __forceinline__ void trinv_level_mfma(double* __restrict__ M, double*
     for (int t = w; t < TILES; t += nw) {            // W[B,A] = -W[B,B] T; W[B,B] lower: k-tiles kt <= it
         const int p = t / (NT * NT), it = (t / NT) % NT, jt = t % NT;
         const int a0 = 2 * p * S, b0 = a0 + S;
+        if (b0 + 16 * it >= 16 * ntl) continue;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
         for (int kt = 0; kt <= it; ++kt) {
 #pragma unroll
@@ -640,16 +543,17 @@ __device__ __forceinline__ void trinv_level_mfma(double* __restrict__ M, double*
 
 // Inverse of the packed lower-triangular block M in place, given the inverses of its eight diagonal tiles.
 // T: 64 * 65 doubles.  All 256 threads; ends on a barrier.
-__device__ __forceinline__ void trinv128_mfma(double* __restrict__ M, const double* __restrict__ Wi8, double* __restrict__ T) {
+__device__ __forceinline__ void trinv128_mfma(double* __restrict__ M, const double* __restrict__ Wi8, double* __restrict__ T,
+                                              int ntl = 8) {
     const int tid = threadIdx.x;
     for (int idx = tid; idx < 8 * 256; idx += blockDim.x) {      // tile inverses into the diagonal tiles
         const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
         if (c <= r) M[tri_off(16 * b + r) + 16 * b + c] = Wi8[b * LEAF_DOUBLES + r * LEAF_P + c];
     }
     __syncthreads();
-    trinv_level_mfma<16>(M, T);
-    trinv_level_mfma<32>(M, T);
-    trinv_level_mfma<64>(M, T);
+    trinv_level_mfma<16>(M, T, ntl);
+    trinv_level_mfma<32>(M, T, ntl);
+    trinv_level_mfma<64>(M, T, ntl);
 }
 
 // defer (MFMA form only): stop after the factor; the inverses of the eight 16x16 diagonal tiles go into the diagonal
@@ -1764,14 +1668,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
 }
 
 // Whole -logL (+ gradient) evaluation of ONE hyper-parameter setting in ONE workgroup, for n <= 128: covariance
-// tiles built in registers, factor and inverse as in the diagonal-block kernel, z = W y, alpha = W^T z, the
+// tiles built in registers, factor and inverse by the diagonal-block kernel's MFMA routines, z = W y, alpha = W^T z, the
 // scalars, then Kinv = W^T W tile by tile out of LDS and the gradient sums.  grid = number of settings: a
 // multi-start fit on ~100 points is one launch instead of ten launches per setting.
 //   nll = n/2 (log 2pi + 1) + n/2 log(theta1) + sum log diag L,  theta1 = y.alpha / n       (mlefcn)
 //   g_t = -1/(2 theta_t) sum_{j != k} (n a_j a_k / (y.a) - Kinv_jk) q_t F_jk   (jacmlefun; F = K0 for RBF, kern_dfac)
 // LDS: W with pitch 129 (the packed copy of L lives in the same space while the inverse runs), scaled inputs, vectors.
 constexpr int SMALL_WP = PB + 1;
-constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 2 * PB + 6 * PB + 4 * GRAD_D + 8;
+constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 6 * PB + 4 * GRAD_D + 8;
 __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __restrict__ Xraw, int xpitch,
                                                              const double* __restrict__ y, int n, int d,
                                                              const double* __restrict__ thetas,
@@ -1781,8 +1685,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
     __shared__ double lds[SMALL_LDS_DOUBLES];
     double* Wl = lds;                         // [128][129]; first the packed L
     double* xs = Wl + PB * SMALL_WP;          // [GRAD_D][128] inputs / theta
-    double* vec = xs + GRAD_D * PB;           // [2][128]
-    double* dg = vec + 2 * PB;                // [128]
+    double* dg = xs + GRAD_D * PB;            // [128] diag L
     double* yv = dg + PB;
     double* zv = yv + PB;
     double* al = zv + PB;
@@ -1822,7 +1725,13 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
             a[rr][cc] = v;
         }
     const int nt = (n + 7) >> 3;               // tile columns that hold data; the rest of the block is the identity pad
-    const int fail = potrf_factor_regs(a, vec, dg, nt);
+    // factor and inverse as in the diagonal-block kernel (register tile factorisation of the 16x16 tiles, everything
+    // else on MFMA), on the packed copy; the product buffer and the tile inverses live in the rest of the W space
+    __shared__ int fail_s;
+    double* Tbuf = Wl + POTRF_LDS_PACKED;
+    double* Wi8 = Tbuf + TRINV_T_DOUBLES;
+    static_assert(POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES <= PB * SMALL_WP, "scratch fits behind the packed block");
+    if (tid == 0) fail_s = -1;
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
@@ -1831,15 +1740,23 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
             if (c <= r) Wl[tri_off(r) + c] = a[rr][cc];
         }
     __syncthreads();
-    potrf_inverse_regs(a, Wl, vec, dg, nt);
-    __syncthreads();                           // every read of the packed L is done
+    potrf128_mfma(Wl, Wi8, &fail_s, (n + 15) >> 4);
+    const int fail = fail_s;
+    if (tid < PB) dg[tid] = Wl[tri_off(tid) + tid];
+    __syncthreads();                           // diag L is saved before the inverse overwrites it
+    trinv128_mfma(Wl, Wi8, Tbuf, (n + 15) >> 4);
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
             const int r = tr * 8 + rr, c = tc * 8 + cc;
-            Wl[r * SMALL_WP + c] = (c <= r) ? a[rr][cc] : 0.0;
+            a[rr][cc] = (c <= r) ? Wl[tri_off(r) + (c <= r ? c : r)] : 0.0;
         }
+    __syncthreads();                           // every read of the packed W is done
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) Wl[(tr * 8 + rr) * SMALL_WP + tc * 8 + cc] = a[rr][cc];
     __syncthreads();
     if (tid < PB) {                            // z = W y (row tid)
         double z = 0.0;
