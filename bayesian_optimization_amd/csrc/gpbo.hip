@@ -68,7 +68,7 @@ struct gpbo_ctx {
     // workspace of the one-workgroup likelihood kernel (n <= 128), kept between calls
     double* sm_buf = nullptr;
     size_t sm_cap = 0;          // doubles
-    std::vector<double> sm_host;
+    double* sm_host = nullptr;  // pinned staging of the same size (pageable memory would be copied through a driver buffer)
 
     // batched likelihood sweep, general path: batch arrays (caller context) and per-lane state, all kept between calls
     double *lb_xraw = nullptr, *lb_th = nullptr, *lb_sg = nullptr, *lb_nll = nullptr, *lb_grad = nullptr;
@@ -952,6 +952,7 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     if (ctx->res_host) hipHostFree(ctx->res_host);
     for (auto e : ctx->pool) hipEventDestroy(e);
     if (ctx->sm_buf) hipFree(ctx->sm_buf);
+    if (ctx->sm_host) hipHostFree(ctx->sm_host);
     if (ctx->lane_graph) hipGraphExecDestroy(ctx->lane_graph);
     for (void* p : {(void*)ctx->lb_xraw, (void*)ctx->lb_th, (void*)ctx->lb_sg, (void*)ctx->lb_nll, (void*)ctx->lb_grad,
                     (void*)ctx->lb_info, (void*)ctx->lane_gpart, (void*)ctx->lane_slot})
@@ -1589,16 +1590,20 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         const size_t n_out = (size_t)B + (size_t)B * d + B;
         if (ctx->sm_cap < n_in + n_out) {
             if (ctx->sm_buf) hipFree(ctx->sm_buf);
+            if (ctx->sm_host) hipHostFree(ctx->sm_host);
             ctx->sm_buf = nullptr;
+            ctx->sm_host = nullptr;
             ctx->sm_cap = 0;
-            HIPCHK(hipMalloc((void**)&ctx->sm_buf, (n_in + n_out) * 8));
-            ctx->sm_cap = n_in + n_out;
+            const size_t cap = 2 * (n_in + n_out);         // room to grow: a multi-start fit calls again and again
+            HIPCHK(hipMalloc((void**)&ctx->sm_buf, cap * 8));
+            HIPCHK(hipHostMalloc((void**)&ctx->sm_host, cap * 8, hipHostMallocDefault));
+            ctx->sm_cap = cap;
         }
-        std::vector<double>& h = ctx->sm_host;
-        h.assign(n_in + n_out, 0.0);
+        double* h = ctx->sm_host;
+        std::fill(h, h + (size_t)d * PB + PB, 0.0);
         for (int t = 0; t < d; ++t)
             for (int64_t i = 0; i < n; ++i) h[(size_t)t * PB + i] = X[i * d + t];
-        double* hy = h.data() + (size_t)d * PB;
+        double* hy = h + (size_t)d * PB;
         for (int64_t i = 0; i < n; ++i) hy[i] = y[i];
         memcpy(hy + PB, thetas, (size_t)B * d * 8);
         memcpy(hy + PB + (size_t)B * d, sigmas, (size_t)B * 8);
@@ -1610,14 +1615,14 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         double* dgrad = dnll + B;
         int* dinfo = reinterpret_cast<int*>(dgrad + (size_t)B * d);
         const auto t0 = std::chrono::steady_clock::now();
-        HIPCHK(hipMemcpyAsync(ctx->sm_buf, h.data(), n_in * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->sm_buf, h, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_lml_small, dim3((unsigned)B), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)dX, (int)PB,
                            (const double*)dy, (int)n, (int)d, (const double*)dth, (const double*)dsg, (int)kernel, grad_out ? 1 : 0,
                            dnll, dgrad, dinfo);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h.data() + n_in, dnll, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h + n_in, dnll, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        const double* onll = h.data() + n_in;
+        const double* onll = h + n_in;
         const double* ograd = onll + B;
         const int* hinfo = reinterpret_cast<const int*>(ograd + (size_t)B * d);
         ctx->tm.fit_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
