@@ -317,6 +317,7 @@ bool chol_potrf_valu() {
 int chol_first_deferred(int nb, int batch) {
     static const int trsm_rows_max = getenv("GPBO_TRSM_ROWS_MAX") ? atoi(getenv("GPBO_TRSM_ROWS_MAX")) : 128;
     if (chol_potrf_valu()) return nb;              // the all-VALU diagonal kernel (comparison runs) always inverts in place
+    if (nb == 1) return nb;                        // a single block has no panel solve: inverting in place saves a launch
     return std::max(0, nb - 1 - trsm_rows_max / std::max(1, batch));      // block rows below the panel, over all slots
 }
 
@@ -340,9 +341,9 @@ void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, 
     const int q = p0;
     const int defer = q >= chol_first_deferred(nb, ctx->batch);
     if (chol_potrf_valu())
-        hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, 0);
+        hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, 0, (int)ctx->n);
     else
-        hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1, 1, S), dim3(potrf_threads), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, defer);
+        hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1, 1, S), dim3(potrf_threads), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, defer, (int)ctx->n);
     if (q + 1 < nb) {
         if (defer)
             hipLaunchKernelGGL(k_trsm_rows, dim3(8 * (nb - q - 1), 1, S), dim3(64), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
@@ -456,7 +457,7 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     const int first_deferred = chol_first_deferred(nb, ctx->batch);
     if (first_deferred < nb)
         hipLaunchKernelGGL(k_trinv_diag, dim3((unsigned)(nb - first_deferred), 1, (unsigned)ctx->batch), dim3(1024), 0, ctx->stream,
-                           (const double*)A, ld, first_deferred, ctx->Dinv, ctx->bs);
+                           (const double*)A, ld, first_deferred, ctx->Dinv, ctx->bs, (int)ctx->n);
     dim3 grid((unsigned)(ctx->n_pad / 64), (unsigned)(ctx->n_pad / 4), (unsigned)ctx->batch);
     hipLaunchKernelGGL(k_zero_upper, grid, dim3(256), 0, ctx->stream, A, (int)ctx->n_pad, ctx->bs);
     HIPCHK(hipGetLastError());

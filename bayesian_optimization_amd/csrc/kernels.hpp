@@ -556,11 +556,18 @@ __device__ __forceinline__ void trinv128_mfma(double* __restrict__ M, const doub
     trinv_level_mfma<64>(M, T, ntl);
 }
 
+// 16-row tiles of diagonal block p that hold data when the matrix has n real rows (the rest of the block, padding up to
+// a multiple of 128, is the identity and is skipped by the MFMA routines)
+__device__ __forceinline__ int data_tiles(int n, int p) {
+    const int t = (n - p * PB + 15) >> 4;
+    return t < 1 ? 1 : (t > 8 ? 8 : t);
+}
+
 // defer (MFMA form only): stop after the factor; the inverses of the eight 16x16 diagonal tiles go into the diagonal
 // tiles of the block's Dinv (all k_trsm_rows needs), the inverse of the whole block is left to k_trinv_diag.
 template <bool MFMA>
 __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
-                                                int* __restrict__ info, double* __restrict__ S, bool defer) {
+                                                int* __restrict__ info, double* __restrict__ S, bool defer, int ntl) {
     __shared__ int fail_s;
     const int tid = threadIdx.x;
     double* blk = A + (long)p * PB * ld + (long)p * PB;
@@ -578,7 +585,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     }
     __syncthreads();
     GPBO_STAMP(4, 1);
-    if (MFMA) potrf128_mfma(S, Wi8, &fail_s);
+    if (MFMA) potrf128_mfma(S, Wi8, &fail_s, ntl);
     else potrf128_lds(S, &fail_s);
     GPBO_STAMP(5, 1);
     if (tid == 0 && fail_s >= 0) atomicCAS(info, 0, p * PB + fail_s + 1);
@@ -600,7 +607,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     }
     __syncthreads();
     GPBO_STAMP(6, 1);
-    if (MFMA) trinv128_mfma(S, Wi8, Tbuf);
+    if (MFMA) trinv128_mfma(S, Wi8, Tbuf, ntl);
     else trinv128_lds(S, Tbuf);
     GPBO_STAMP(7, 1);
     for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
@@ -620,9 +627,10 @@ constexpr int POTRF_MFMA_THREADS = 1024;        // 16 waves: the MFMA phases are
 template <bool MFMA>
 __global__ __launch_bounds__(MFMA ? POTRF_MFMA_THREADS : POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
                                                               double* __restrict__ Dinv, int* __restrict__ info, BatchStride bs,
-                                                              int defer) {
+                                                              int defer, int n) {
     __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + (MFMA ? 8 * LEAF_DOUBLES : 0)];
-    potrf_diag_body<MFMA>(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S, defer != 0);
+    potrf_diag_body<MFMA>(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S, defer != 0,
+                          data_tiles(n, p));
 }
 
 // Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(64) void k_trsm_rows(double* __restrict__ A, long l
 // Inverse of factored diagonal blocks p0 + blockIdx.x, from L (in A) and the tile inverses (diagonal tiles of Dinv),
 // for the blocks whose factorisation kernel left it out (it is not needed by k_trsm_rows).
 __global__ __launch_bounds__(1024) void k_trinv_diag(const double* __restrict__ A, long ld, int p0, double* __restrict__ Dinv,
-                                                    BatchStride bs) {
+                                                    BatchStride bs, int n) {
     __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES];
     const int tid = threadIdx.x, p = p0 + blockIdx.x;
     const double* blk = A + blockIdx.z * bs.mat + (long)p * PB * ld + (long)p * PB;
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(1024) void k_trinv_diag(const double* __restrict__ 
         Wi8[b * LEAF_DOUBLES + r * LEAF_P + c] = dinv[(16 * b + r) * PB + 16 * b + c];
     }
     __syncthreads();
-    trinv128_mfma(S, Wi8, Tbuf);
+    trinv128_mfma(S, Wi8, Tbuf, data_tiles(n, p));
     for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
         const int r = idx >> 6, c = (idx & 63) * 2;
         f64x2 v;

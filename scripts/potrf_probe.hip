@@ -17,7 +17,7 @@ template <bool MFMA> int run(int threads) {
         { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0);
-        k_potrf_diag<MFMA><<<1, threads>>>(dA, n, 0, dinv, info, BatchStride{}, 0);
+        k_potrf_diag<MFMA><<<1, threads>>>(dA, n, 0, dinv, info, BatchStride{}, 0, n);
         (void)hipEventRecord(e1);
         (void)hipDeviceSynchronize();
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
