@@ -301,7 +301,8 @@ int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, doub
 // updated once with K = 128*group.
 int chol_group(int nb) {
     if (const char* e = getenv("GPBO_CHOL_GROUP")) return std::max(1, atoi(e));
-    if (nb <= 40) return 1;        // small n: every launch is latency bound, one update per panel is the shortest chain
+    if (nb <= 56) return 1;        // small n: every launch is latency bound, one update per panel is the shortest chain
+    if (nb <= 80) return 2;        // measured: n = 8192: 7.70 / 7.65 / 7.92 ms, n = 12288: 19.1 / 17.7 / 17.5 ms with 1 / 2 / 4
     return nb >= 192 ? 8 : 4;      // large n: a longer K makes the bulk update more efficient
 }
 
