@@ -183,6 +183,90 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
 }
 
 // ---------------------------------------------------------------------------------------
+// Half-height form: one 256-thread workgroup computes a 64 x 128 tile (waves 2 x 2, each 32 x 64 = 2 x 4 MFMA tiles), both
+// operands row-major with k contiguous.  For products whose 128 x 128 tiles are too few to fill the chip (the trailing
+// updates of a small factorisation): a 128 x 128 x 128 tile is 13.7 us of MFMA time on one CU whatever the grid, twice
+// as many half tiles finish in half of that.  Per flop it moves 1.5x the operand bytes of the square tile, so it is not
+// for large grids.  LDS: 2 x (64 + 128) x 18 doubles = 55,296 B.
+constexpr int HALF_M = 64;
+constexpr int HALF_A_DOUBLES = HALF_M * LDS_RK;             // 1152
+constexpr int HALF_BUF_DOUBLES = HALF_A_DOUBLES + 128 * LDS_RK;
+constexpr int HALF_LDS_DOUBLES = 2 * HALF_BUF_DOUBLES;      // 6912 doubles
+
+struct StageHalf {
+    f64x2 a[2];
+    f64x2 b[4];
+};
+
+__device__ __forceinline__ void load_half(StageHalf& s, const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                          int k0, int tid) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int q = tid + 256 * p;
+        s.a[p] = *reinterpret_cast<const f64x2*>(A + (long)(q >> 3) * lda + k0 + 2 * (q & 7));
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int q = tid + 256 * p;
+        s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(q >> 3) * ldb + k0 + 2 * (q & 7));
+    }
+}
+
+__device__ __forceinline__ void store_half(const StageHalf& s, double* lds, int tid) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int q = tid + 256 * p;
+        *reinterpret_cast<f64x2*>(lds + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.a[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int q = tid + 256 * p;
+        *reinterpret_cast<f64x2*>(lds + HALF_A_DOUBLES + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.b[p];
+    }
+}
+
+// acc[ta][tb][r] of this lane is element (row, col) of the 64 x 128 tile with
+//   row = (w >> 1) * 32 + ta * 16 + (lane >> 4) + 4 r,  col = (w & 1) * 64 + tb * 16 + (lane & 15).
+__device__ __forceinline__ void gemm_tile_64x128(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                                 int k_begin, int k_end, f64x4 (&acc)[2][4], double* lds) {
+    if (k_begin >= k_end) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    StageHalf st;
+    load_half(st, A, lda, B, ldb, k_begin, tid);
+    store_half(st, lds, tid);
+    __syncthreads();
+    int buf = 0;
+    const int a_off = (wr * 32 + (lane & 15)) * LDS_RK + (lane >> 4);
+    const int b_off = HALF_A_DOUBLES + (wc * 64 + (lane & 15)) * LDS_RK + (lane >> 4);
+    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
+        load_half(st, A, lda, B, ldb, kn, tid);
+        const double* a_l = lds + buf * HALF_BUF_DOUBLES + a_off;
+        const double* b_l = lds + buf * HALF_BUF_DOUBLES + b_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[2], bf[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) af[t] = a_l[kk * 4 + t * 16 * LDS_RK];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = b_l[kk * 4 + t * 16 * LDS_RK];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (kk == 2) store_half(st, lds + (buf ^ 1) * HALF_BUF_DOUBLES, tid);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Wide form: one 512-thread workgroup (eight waves, 2 x 4, each still 64x64) computes a 128 x 256 tile
 //   acc(i,j) = sum_k A(i,k) B(k,j),  A row-major with k contiguous (a row panel of W), B k-major with j contiguous.
 // Per k-step a thread issues six 16-byte global loads instead of eight (the A tile is shared by twice as many MFMAs),

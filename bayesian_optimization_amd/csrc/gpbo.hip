@@ -322,6 +322,12 @@ int chol_first_deferred(int nb, int batch) {
     return std::max(0, nb - 1 - trsm_rows_max / std::max(1, batch));      // block rows below the panel, over all slots
 }
 
+// Trailing updates with at most this many 128 x 128 tiles (over all slots) run on half tiles (k_syrk_update_half).
+long syrk_half_max() {
+    static const long v = getenv("GPBO_SYRK_HALF_MAX") ? atol(getenv("GPBO_SYRK_HALF_MAX")) : 1024;
+    return v;
+}
+
 // F(group): the latency-bound part.  Needs the group's block columns up to date.
 // Inside the group the panels are applied to the group's own block columns recursively: factor the left half, update
 // the right half's columns with the whole left half at once (K = 128 * half), factor the right half.  The number of
@@ -335,7 +341,12 @@ void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, 
     if (g > 1) {
         const int h = g / 2, c0 = p0 + h;          // columns c0 .. p0 + g - 1 take panels p0 .. c0 - 1
         chol_factor_group(st, ctx, A, info_dev, p0, h);
-        hipLaunchKernelGGL(k_syrk_update<false>, dim3(g - h, nb - c0, S), dim3(GEMM_THREADS), 0, st, A, ld, c0, c0, p0 * PB, h * PB, ctx->bs);
+        if ((long)(g - h) * (nb - c0) * S <= syrk_half_max())
+            hipLaunchKernelGGL(k_syrk_update_half<false>, dim3(2 * (g - h), nb - c0, S), dim3(GEMM_THREADS), 0, st, A, ld, c0, c0,
+                               p0 * PB, h * PB, ctx->bs);
+        else
+            hipLaunchKernelGGL(k_syrk_update<false>, dim3(g - h, nb - c0, S), dim3(GEMM_THREADS), 0, st, A, ld, c0, c0, p0 * PB, h * PB,
+                               ctx->bs);
         chol_factor_group(st, ctx, A, info_dev, c0, g - h);
         return;
     }
@@ -449,10 +460,13 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
             const int g = std::min(G, nb - p0);
             chol_factor_group(ctx->stream, ctx, A, info_dev, p0, g);
             const int T = nb - (p0 + g);
-            if (T > 0) {
-                hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T * (T + 1) / 2), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
+            const long tiles = (long)T * (T + 1) / 2;
+            if (T > 0 && tiles * ctx->batch <= syrk_half_max())
+                hipLaunchKernelGGL(k_syrk_update_half<true>, dim3((unsigned)(2 * tiles), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
                                    ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
-            }
+            else if (T > 0)
+                hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)tiles, 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
+                                   ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
         }
     }
     const int first_deferred = chol_first_deferred(nb, ctx->batch);

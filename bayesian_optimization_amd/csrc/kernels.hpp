@@ -784,6 +784,47 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restr
             for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = -acc[ta][tb][r];
 }
 
+// The same update on 64 x 128 half tiles (gemm_tile_64x128), for launches whose 128 x 128 tiles would leave most of the
+// chip idle: twice the workgroups, each with half the MFMA time.  Grid: 2 x the tiles of k_syrk_update, blockIdx.x =
+// 2 * tile + half (TRI) or blockIdx.x = 2 * column + half, blockIdx.y = row (!TRI).
+template <bool TRI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update_half(double* __restrict__ A, long ld, int b0, int jb0, int kcol0,
+                                                                   int klen, BatchStride bs) {
+    A += blockIdx.z * bs.mat;
+    const int h = blockIdx.x & 1;
+    int ib, jb;
+    if (TRI) {
+        int i, j;
+        tri_decode(blockIdx.x >> 1, i, j);
+        ib = b0 + i;
+        jb = b0 + j;
+    } else {
+        ib = b0 + blockIdx.y;
+        jb = jb0 + (blockIdx.x >> 1);
+        __builtin_amdgcn_s_setprio(2);
+    }
+    __shared__ double lds[HALF_LDS_DOUBLES];
+    const double* Pi = A + ((long)ib * PB + h * HALF_M) * ld + kcol0;
+    const double* Pj = A + (long)jb * PB * ld + kcol0;
+    double* C = A + ((long)ib * PB + h * HALF_M) * ld + (long)jb * PB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 64 + (lane & 15);
+    f64x4 acc[2][4];            // start at -C, store -(acc): see k_syrk_update
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16];
+    gemm_tile_64x128(Pi, ld, Pj, ld, 0, klen, acc, lds);
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
+}
+
 // Zero the strict upper triangle (the factorisation leaves stale values there).
 __global__ __launch_bounds__(256) void k_zero_upper(double* __restrict__ A, int n_pad, BatchStride bs) {
     A += blockIdx.z * bs.mat;
