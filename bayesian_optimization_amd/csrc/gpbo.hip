@@ -82,6 +82,7 @@ struct gpbo_ctx {
     size_t params_cap = PARAMS_DOUBLES, slot_cap = 0;
     int64_t alloc_gen = 0;      // bumped whenever a buffer a captured launch sequence names is (re)allocated
     bool no_timing = false;     // set while a launch sequence is captured into a graph
+    bool timing_off = false;    // gpbo_set_timing(ctx, 0)
     int batch = 1;              // > 1: a batched context, every model buffer holds `batch` slots (see BatchStride)
     BatchStride bs;
     gpbo_ctx* lml_lock = nullptr;   // the batched work context of the likelihood sweep (caller context only)
@@ -175,14 +176,14 @@ struct Scope {
     gpbo_ctx* ctx;
     EvRec r;
     Scope(gpbo_ctx* c, int cat) : ctx(c) {
-        if (c->no_timing) return;
+        if (c->no_timing || c->timing_off) return;
         r.cat = cat;
         r.a = ev_get(c);
         r.b = ev_get(c);
         hipEventRecord(r.a, c->stream);
     }
     ~Scope() {
-        if (ctx->no_timing) return;
+        if (ctx->no_timing || ctx->timing_off) return;
         hipEventRecord(r.b, ctx->stream);
         ctx->recs.push_back(r);
     }
@@ -1207,6 +1208,12 @@ int gpbo_cond_estimate(gpbo_ctx* ctx, double* cond_out) {
     HIPCHK(hipMemcpyAsync(mm, ctx->red_v, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *cond_out = (mm[1] / mm[0]) * (mm[1] / mm[0]);
+    return GPBO_OK;
+}
+
+int gpbo_set_timing(gpbo_ctx* ctx, int32_t enabled) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    ctx->timing_off = (enabled == 0);
     return GPBO_OK;
 }
 

@@ -69,6 +69,10 @@ class GP:
         self._check(self._lib.gpbo_last_timings(self._h, C.byref(t)))
         return t.as_dict()
 
+    def set_timing(self, enabled: bool):
+        """Per-phase event timing (what timings() reads) on or off; off saves the events' cost in tight loops of step calls."""
+        self._check(self._lib.gpbo_set_timing(self._h, 1 if enabled else 0))
+
     def set_chunk(self, chunk: int):
         self._check(self._lib.gpbo_set_chunk(self._h, int(chunk)))
 

@@ -209,6 +209,11 @@ int gpbo_get_factor(gpbo_ctx* ctx, double* L_out, double* alpha_out);
 
 int gpbo_last_timings(gpbo_ctx* ctx, gpbo_timings* out);
 
+/* Per-phase event timing of the calls on this context on (1, the default) or off (0).  No counterpart in the reference:
+ * the events behind gpbo_last_timings cost a few microseconds each, which shows in a loop of gpbo_append_acquire calls
+ * (about 1 % of an iteration); a caller that does not read the timings switches them off, or on for a sample of calls. */
+int gpbo_set_timing(gpbo_ctx* ctx, int32_t enabled);
+
 /* Scalars of the current model: theta1 (BayesOpt_v4.ipynb:144), -logL (:164), max(yTrain), n.  Any may be NULL. */
 int gpbo_model_scalars(gpbo_ctx* ctx, double* theta1_out, double* nll_out, double* y_max_out, int64_t* n_out);
 
