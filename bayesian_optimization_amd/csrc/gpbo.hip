@@ -300,8 +300,10 @@ int launch_kernel_matrix(gpbo_ctx* ctx, double* K, const double* scale_ptr, doub
 // inside a group each panel is factored (diagonal block in one workgroup, then the panel solve) and the group's own
 // block columns are brought up to date recursively (chol_factor_group); after the group the whole trailing matrix is
 // updated once with K = 128*group.
-int chol_group(int nb) {
+int chol_group(int nb, int batch) {
     if (const char* e = getenv("GPBO_CHOL_GROUP")) return std::max(1, atoi(e));
+    if (batch >= 8 && nb >= 64) return 16;      // slots in lockstep fill the chip between them: the chain matters less than K
+                                                // (n = 16384, 16 slots: 14.30 / 14.45 / 14.50 settings/s with 4 / 8 / 16)
     if (nb <= 56) return 1;        // small n: every launch is latency bound, one update per panel is the shortest chain
     if (nb <= 80) return 2;        // measured: n = 8192: 7.70 / 7.65 / 7.92 ms, n = 12288: 19.1 / 17.7 / 17.5 ms with 1 / 2 / 4
     return nb >= 192 ? 8 : 4;      // large n: a longer K makes the bulk update more efficient
@@ -412,7 +414,7 @@ int launch_cholesky_lookahead(gpbo_ctx* ctx, double* A, int* info_dev) {
     HIPCHK(hipEventRecord(ev, ctx->stream));
     HIPCHK(hipStreamWaitEvent(P, ev, 0));
     if (masked) HIPCHK(hipStreamWaitEvent(B, ev, 0));
-    const int G = chol_group(nb);
+    const int G = chol_group(nb, ctx->batch);
     for (int p0 = 0; p0 < nb; p0 += G) {
         const int g = std::min(G, nb - p0);
         chol_factor_group(P, ctx, A, info_dev, p0, g);
@@ -447,7 +449,7 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     Scope s(ctx, T_CHOL);
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
-    const int G = chol_group(nb);
+    const int G = chol_group(nb, ctx->batch);
     // The two-stream form is opt-in (GPBO_CHOL_LOOKAHEAD=1): it is 10-25 % faster from n = 16384 up with the GPU to
     // itself, but with other processes on the same GPU (two ranks and a parent sharing one card) every cross-stream
     // wait took ~0.5 s and progress then stopped: with more user queues than hardware queue slots the scheduler
