@@ -187,10 +187,10 @@ __device__ __forceinline__ void gemm_tile_128(const double* __restrict__ A, long
 // operands row-major with k contiguous.  For products whose 128 x 128 tiles are too few to fill the chip (the trailing
 // updates of a small factorisation): a 128 x 128 x 128 tile is 13.7 us of MFMA time on one CU whatever the grid, twice
 // as many half tiles finish in half of that.  Per flop it moves 1.5x the operand bytes of the square tile, so it is not
-// for large grids.  LDS: 2 x (64 + 128) x 18 doubles = 55,296 B.
+// for large grids.  LDS: 2 x (64 x 18 + 2304) doubles = 55,296 B (the B image is 128 x 18 row-major or 16 x 144 k-major).
 constexpr int HALF_M = 64;
 constexpr int HALF_A_DOUBLES = HALF_M * LDS_RK;             // 1152
-constexpr int HALF_BUF_DOUBLES = HALF_A_DOUBLES + 128 * LDS_RK;
+constexpr int HALF_BUF_DOUBLES = HALF_A_DOUBLES + TILE_DOUBLES;
 constexpr int HALF_LDS_DOUBLES = 2 * HALF_BUF_DOUBLES;      // 6912 doubles
 
 struct StageHalf {
@@ -198,6 +198,8 @@ struct StageHalf {
     f64x2 b[4];
 };
 
+// B_KCONTIG as in load_tile: true = B row-major with k contiguous, false = k-major (element (j, k) at B[k * ldb + j]).
+template <bool B_KCONTIG>
 __device__ __forceinline__ void load_half(StageHalf& s, const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                           int k0, int tid) {
 #pragma unroll
@@ -208,10 +210,12 @@ __device__ __forceinline__ void load_half(StageHalf& s, const double* __restrict
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int q = tid + 256 * p;
-        s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(q >> 3) * ldb + k0 + 2 * (q & 7));
+        if (B_KCONTIG) s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(q >> 3) * ldb + k0 + 2 * (q & 7));
+        else s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(k0 + (q >> 6)) * ldb + 2 * (q & 63));
     }
 }
 
+template <bool B_KCONTIG>
 __device__ __forceinline__ void store_half(const StageHalf& s, double* lds, int tid) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -221,12 +225,14 @@ __device__ __forceinline__ void store_half(const StageHalf& s, double* lds, int 
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int q = tid + 256 * p;
-        *reinterpret_cast<f64x2*>(lds + HALF_A_DOUBLES + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.b[p];
+        if (B_KCONTIG) *reinterpret_cast<f64x2*>(lds + HALF_A_DOUBLES + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.b[p];
+        else *reinterpret_cast<f64x2*>(lds + HALF_A_DOUBLES + (q >> 6) * LDS_LD + 2 * (q & 63)) = s.b[p];
     }
 }
 
 // acc[ta][tb][r] of this lane is element (row, col) of the 64 x 128 tile with
 //   row = (w >> 1) * 32 + ta * 16 + (lane >> 4) + 4 r,  col = (w & 1) * 64 + tb * 16 + (lane & 15).
+template <bool B_KCONTIG = true>
 __device__ __forceinline__ void gemm_tile_64x128(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                                  int k_begin, int k_end, f64x4 (&acc)[2][4], double* lds) {
     if (k_begin >= k_end) return;
@@ -234,15 +240,15 @@ __device__ __forceinline__ void gemm_tile_64x128(const double* __restrict__ A, l
     const int lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     StageHalf st;
-    load_half(st, A, lda, B, ldb, k_begin, tid);
-    store_half(st, lds, tid);
+    load_half<B_KCONTIG>(st, A, lda, B, ldb, k_begin, tid);
+    store_half<B_KCONTIG>(st, lds, tid);
     __syncthreads();
     int buf = 0;
     const int a_off = (wr * 32 + (lane & 15)) * LDS_RK + (lane >> 4);
-    const int b_off = HALF_A_DOUBLES + (wc * 64 + (lane & 15)) * LDS_RK + (lane >> 4);
+    const int b_off = HALF_A_DOUBLES + frag_base<B_KCONTIG>(lane, wc * 64);
     for (int k0 = k_begin; k0 < k_end; k0 += TK) {
         const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
-        load_half(st, A, lda, B, ldb, kn, tid);
+        load_half<B_KCONTIG>(st, A, lda, B, ldb, kn, tid);
         const double* a_l = lds + buf * HALF_BUF_DOUBLES + a_off;
         const double* b_l = lds + buf * HALF_BUF_DOUBLES + b_off;
 #pragma unroll
@@ -251,7 +257,7 @@ __device__ __forceinline__ void gemm_tile_64x128(const double* __restrict__ A, l
 #pragma unroll
             for (int t = 0; t < 2; ++t) af[t] = a_l[kk * 4 + t * 16 * LDS_RK];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bf[t] = b_l[kk * 4 + t * 16 * LDS_RK];
+            for (int t = 0; t < 4; ++t) bf[t] = b_l[kk * frag_kstride<B_KCONTIG>() + t * frag_tstride<B_KCONTIG>()];
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ta = 0; ta < 2; ++ta)
@@ -259,7 +265,7 @@ __device__ __forceinline__ void gemm_tile_64x128(const double* __restrict__ A, l
                 for (int tb = 0; tb < 4; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-            if (kk == 2) store_half(st, lds + (buf ^ 1) * HALF_BUF_DOUBLES, tid);
+            if (kk == 2) store_half<B_KCONTIG>(st, lds + (buf ^ 1) * HALF_BUF_DOUBLES, tid);
         }
         __syncthreads();
         buf ^= 1;

@@ -546,11 +546,18 @@ int launch_inverse(gpbo_ctx* ctx, const double* L, double* W, double* T) {
     const unsigned S = (unsigned)ctx->batch;
     HIPCHK(hipMemsetAsync(W, 0, (size_t)ctx->n_pad * ctx->n_pad * S * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(k_inv_copy_diag, dim3(nb, 1, S), dim3(256), 0, ctx->stream, W, ld, (const double*)ctx->Dinv, ctx->bs);
+    static const long inv_half_max = getenv("GPBO_INV_HALF_MAX") ? atol(getenv("GPBO_INV_HALF_MAX")) : 1024;
     for (int sb = 1; sb < nb; sb *= 2) {
         const int pairs = (nb + 2 * sb - 1) / (2 * sb);
         dim3 grid(sb, sb, pairs * S);  // step1: (ib, jb), step2: (jb, reversed ib): the slow index orders tiles longest first
-        hipLaunchKernelGGL(k_inv_step1, grid, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb, ctx->bs);
-        hipLaunchKernelGGL(k_inv_step2, grid, dim3(GEMM_THREADS), 0, ctx->stream, W, (const double*)T, ld, sb, nb, ctx->bs);
+        if ((long)sb * sb * pairs * S <= inv_half_max) {      // too few tiles for the chip: half tiles
+            dim3 gh(2 * sb, sb, pairs * S);
+            hipLaunchKernelGGL(k_inv_step1<true>, gh, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb, ctx->bs);
+            hipLaunchKernelGGL(k_inv_step2<true>, gh, dim3(GEMM_THREADS), 0, ctx->stream, W, (const double*)T, ld, sb, nb, ctx->bs);
+            continue;
+        }
+        hipLaunchKernelGGL(k_inv_step1<false>, grid, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb, ctx->bs);
+        hipLaunchKernelGGL(k_inv_step2<false>, grid, dim3(GEMM_THREADS), 0, ctx->stream, W, (const double*)T, ld, sb, nb, ctx->bs);
     }
     HIPCHK(hipGetLastError());
     return GPBO_OK;

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update_half(double* __
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16];
-    gemm_tile_64x128(Pi, ld, Pj, ld, 0, klen, acc, lds);
+    gemm_tile_64x128<true>(Pi, ld, Pj, ld, 0, klen, acc, lds);
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
@@ -848,6 +848,9 @@ __global__ __launch_bounds__(256) void k_inv_copy_diag(double* __restrict__ W, l
 }
 
 // step 1: T[B,A] = L[B,A] * W[A,A]      (W[A,A] lower triangular: k >= j)
+// HALF (both steps): 64 x 128 half tiles, blockIdx.x = 2 * (x index) + half, for the levels whose 128 x 128 tiles are too
+// few to fill the chip (see gemm_tile_64x128); same sums in the same order.
+template <bool HALF>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __restrict__ L, const double* __restrict__ W,
                                                             double* __restrict__ T, long ld, int sb, int nb, BatchStride bs) {
     const int pairs = (nb + 2 * sb - 1) / (2 * sb);      // gridDim.z = pairs * slots
@@ -857,8 +860,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __r
     T += slot * bs.mat;
     const int a0 = 2 * q * sb, b0 = a0 + sb;
     const int rows = min(sb, nb - b0);
-    const int ib = blockIdx.x, jb = blockIdx.y;      // jb slow: the long tiles (small jb) are dispatched first
+    const int ib = HALF ? blockIdx.x >> 1 : blockIdx.x, jb = blockIdx.y;      // jb slow: the long tiles (small jb) are dispatched first
     if (ib >= rows) return;
+    if (HALF) {
+        __shared__ double ldh[HALF_LDS_DOUBLES];
+        const int h = blockIdx.x & 1;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 64 + (lane & 15);
+        f64x4 acc[2][4];
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        const double* Ap = L + ((long)(b0 + ib) * PB + h * HALF_M) * ld + (long)a0 * PB;
+        const double* Bp = W + (long)a0 * PB * ld + (long)(a0 + jb) * PB;
+        gemm_tile_64x128<false>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, ldh);
+        double* C = T + ((long)(b0 + ib) * PB + h * HALF_M) * ld + (long)(a0 + jb) * PB;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = acc[ta][tb][r];
+        return;
+    }
     __shared__ double lds[GEMM_LDS_DOUBLES];
     f64x4 acc[4][4];
     acc_zero(acc);
@@ -875,6 +900,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __r
 }
 
 // step 2: W[B,A] = - W[B,B] * T[B,A]    (W[B,B] lower triangular: k <= i)
+template <bool HALF>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restrict__ W, const double* __restrict__ T, long ld,
                                                             int sb, int nb, BatchStride bs) {
     const int pairs = (nb + 2 * sb - 1) / (2 * sb);
@@ -883,8 +909,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
     T += slot * bs.mat;
     const int a0 = 2 * q * sb, b0 = a0 + sb;
     const int rows = min(sb, nb - b0);
-    const int ib = rows - 1 - (int)blockIdx.y, jb = blockIdx.x;      // long tiles (large ib) first
+    const int ib = rows - 1 - (int)blockIdx.y, jb = HALF ? blockIdx.x >> 1 : blockIdx.x;      // long tiles (large ib) first
     if (ib < 0) return;
+    if (HALF) {
+        __shared__ double ldh[HALF_LDS_DOUBLES];
+        const int h = blockIdx.x & 1;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 64 + (lane & 15);
+        f64x4 acc[2][4];
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        const double* Ap = W + ((long)(b0 + ib) * PB + h * HALF_M) * ld + (long)b0 * PB;
+        const double* Bp = T + (long)b0 * PB * ld + (long)(a0 + jb) * PB;
+        // W[B,B] is lower triangular: the upper half of the rows ends 64 columns earlier (those products are exact zeros)
+        gemm_tile_64x128<false>(Ap, ld, Bp, ld, 0, ib * PB + (h + 1) * HALF_M, acc, ldh);
+        double* C = W + ((long)(b0 + ib) * PB + h * HALF_M) * ld + (long)(a0 + jb) * PB;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
+        return;
+    }
     __shared__ double lds[GEMM_LDS_DOUBLES];
     f64x4 acc[4][4];
     acc_zero(acc);
