@@ -37,7 +37,10 @@ for c in range(cases):
         worst[k] = max(worst[k], e[k])
     top2 = np.sort(ei_o)[-2:] if m > 1 else np.array([0, 1.0])
     tie = (top2[1] - top2[0]) <= 1e-9 * abs(top2[1])
-    ok = e['mu'] <= 1e-10 and e['var'] <= 1e-8 and e['ei'] <= 1e-8 and e['nll'] <= 1e-10 and (idx == int(np.argmax(ei_o)) or tie) \
+    cond = float(np.linalg.cond(st['L2'] if 'L2' in st and st['L2'] is not None else st['L1'])) ** 2      # of the factored matrix
+    e['cond'] = cond
+    # the mean carries cond * eps of solve error whatever computes it: 1e-10 up to cond ~ 2e5, the same multiple of cond beyond
+    ok = e['mu'] <= max(1e-10, 5e-16 * cond) and e['var'] <= 1e-8 and e['ei'] <= 1e-8 and e['nll'] <= 1e-10 and (idx == int(np.argmax(ei_o)) or tie) \
         and mu_max == mu.max() and idx == int(np.argmax(ei))
     if not ok:
         bad += 1
