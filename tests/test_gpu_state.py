@@ -1,10 +1,12 @@
 """GPU: context state that earlier calls leave behind must never be read stale (work buffers of the likelihood sweep,
 a posterior uploaded without candidates, a model padded for appends handed to another context, device-generated candidates)."""
+import os
+
 import numpy as np
 import pytest
 
 import bayesian_optimization_amd as bo
-from conftest import TOL_MU, TOL_VAR, relmax
+from conftest import ROOT, TOL_MU, TOL_VAR, relmax
 from oracle import gp_oracle as o
 
 pytestmark = pytest.mark.gpu
@@ -143,3 +145,47 @@ def test_fused_loop_step_equals_append_then_acquire():
         assert ga.n == gb.n == 52 and ga.theta1 == gb.theta1 and ga.nll == gb.nll and ga.y_max == gb.y_max
         ga.close()
         gb.close()
+
+
+def test_factorisation_kernel_choices_agree():
+    """The factorisation picks its kernels by size (register-resident or tile-engine panel solve, block inverses inside the
+    diagonal kernel or after the factorisation, whole or half tiles for the trailing update and the inverse).  Forced to
+    the forms that large problems use, a mid-size fit must give the same model: theta1, -logL, factor and posterior."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, json, numpy as np
+sys.path.insert(0, os.getcwd())
+from bayesian_optimization_amd import GP, synth
+n, d = 700, 3
+X = synth.uniform(31, n * d).reshape(n, d)
+y = np.sin(3 * X.sum(1)) + 0.1 * synth.normal(32, n)
+Xs = synth.uniform(33, 500 * d).reshape(500, d)
+gp = GP(0)
+gp.fit(X, y, np.array([0.4, 0.5, 0.6]), 0.05)
+mu, var, ei, idx, _, _ = gp.predict_ei(Xs, 0.01)
+L, a = gp.factor()
+nll, g, st = gp.lml_batch(X, y, np.array([[0.4, 0.5, 0.6], [0.3, 0.3, 0.3]]), [0.05, 0.1], grad=True)
+np.savez(sys.argv[1], mu=mu, var=var, L=L, a=a, th1=gp.theta1, nll=gp.nll, idx=idx, lml=nll, g=g)
+'''
+    outs = []
+    forms = [{}, {'GPBO_TRSM_ROWS_MAX': '0', 'GPBO_SYRK_HALF_MAX': '0', 'GPBO_INV_HALF_MAX': '0'},
+             {'GPBO_CHOL_GROUP': '4', 'GPBO_SYRK_HALF_MAX': '100000', 'GPBO_INV_HALF_MAX': '100000'}]
+    for k, env_add in enumerate(forms):
+        path = os.path.join(ROOT, 'gpurun_out', 'forms_%d.npz' % k)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        env = dict(os.environ, **env_add)
+        proc = subprocess.run([sys.executable, '-c', code, path], env=env, cwd=ROOT, capture_output=True, text=True, timeout=150)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        outs.append(np.load(path))
+    ref = outs[0]
+    rel = lambda p, q: float(np.max(np.abs(p - q)) / np.max(np.abs(q)))
+    # the forms differ in rounding only (substitution against multiplication by an explicit inverse in the panel solve);
+    # what that leaves scales with the conditioning (here ~1e4): three orders of magnitude below the parity targets
+    for o2 in outs[1:]:
+        assert abs(float(o2['th1']) - float(ref['th1'])) <= 1e-12 * float(ref['th1'])
+        assert abs(float(o2['nll']) - float(ref['nll'])) <= 1e-12 * abs(float(ref['nll']))
+        assert rel(o2['L'], ref['L']) <= 1e-11 and rel(o2['a'], ref['a']) <= 1e-10
+        assert rel(o2['mu'], ref['mu']) <= 1e-10 and rel(o2['var'], ref['var']) <= 1e-10 and int(o2['idx']) == int(ref['idx'])
+        assert rel(o2['lml'], ref['lml']) <= 1e-12 and rel(o2['g'], ref['g']) <= 1e-8
