@@ -75,6 +75,8 @@ SIGNATURES = {
     'gpbo_cond_estimate': (C.c_int, [C.c_void_p, _dp]),
     'gpbo_last_timings': (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     'gpbo_set_timing': (C.c_int, [C.c_void_p, C.c_int32]),
+    'gpbo_descent_small': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_double, C.c_int32, C.c_double,
+                                    C.c_double, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _i32p, _i32p]),
     'gpbo_state_describe': (C.c_int, [C.c_void_p, C.POINTER(StateDesc)]),
     'gpbo_state_alloc': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     'gpbo_state_commit': (C.c_int, [C.c_void_p, C.c_double]),

@@ -1220,6 +1220,80 @@ int gpbo_cond_estimate(gpbo_ctx* ctx, double* cond_out) {
     return GPBO_OK;
 }
 
+int gpbo_descent_small(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, const double* W0, int32_t nruns,
+                       double sigmaY, int32_t kernel, double alpha, double beta, int32_t norm, int32_t steprule, int32_t max_its,
+                       double* w_hist_out, double* c_hist_out, int32_t* count_out, int32_t* flag_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!X || !y || !W0 || !w_hist_out || !c_hist_out || !count_out || !flag_out) BADARG("descent_small: null argument");
+    if (n <= 0 || n > PB || d <= 0 || d > GRAD_D) BADARG("descent_small: need 1 <= n <= 128 and 1 <= d <= 16");
+    if (nruns <= 0 || max_its < 0 || max_its > (1 << 24)) BADARG("descent_small: need nruns >= 1 and 0 <= max_its <= 2^24");
+    if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN52) BADARG("descent_small: unknown kernel");
+    if (norm < 0 || norm > 2 || steprule < 0 || steprule > 1) BADARG("descent_small: unknown norm or step rule");
+    if (!(sigmaY >= 0)) BADARG("descent_small: sigmaY must be >= 0");
+    for (int64_t i = 0; i < (int64_t)nruns * d; ++i)
+        if (!(W0[i] != 0.0) || !std::isfinite(W0[i])) BADARG("descent_small: starting points must be finite and non-zero");
+    HIPCHK(hipSetDevice(ctx->device));
+    // one device block: [Xraw d*128][y 128][W0 nruns*d] in, [hist_w][hist_c][count, flag as int32] out; staged through
+    // pinned memory like the one-workgroup likelihood path, whose buffers it shares
+    const size_t H = (size_t)max_its + 1;
+    const size_t n_in = (size_t)d * PB + PB + (size_t)nruns * d;
+    const size_t n_hw = (size_t)nruns * H * d, n_hc = (size_t)nruns * H, n_ints = (size_t)nruns;      // 2 int32 per double slot
+    const size_t n_out = n_hw + n_hc + n_ints;
+    if (ctx->sm_cap < n_in + n_out) {
+        if (ctx->sm_buf) hipFree(ctx->sm_buf);
+        if (ctx->sm_host) hipHostFree(ctx->sm_host);
+        ctx->sm_buf = nullptr;
+        ctx->sm_host = nullptr;
+        ctx->sm_cap = 0;
+        const size_t cap = n_in + n_out + 4096;
+        HIPCHK(hipMalloc((void**)&ctx->sm_buf, cap * 8));
+        HIPCHK(hipHostMalloc((void**)&ctx->sm_host, cap * 8, hipHostMallocDefault));
+        ctx->sm_cap = cap;
+    }
+    double* h = ctx->sm_host;
+    std::fill(h, h + (size_t)d * PB + PB, 0.0);
+    for (int t = 0; t < d; ++t)
+        for (int64_t i = 0; i < n; ++i) h[(size_t)t * PB + i] = X[i * d + t];
+    for (int64_t i = 0; i < n; ++i) h[(size_t)d * PB + i] = y[i];
+    memcpy(h + (size_t)d * PB + PB, W0, (size_t)nruns * d * 8);
+    double* dX = ctx->sm_buf;
+    double* dy = dX + (size_t)d * PB;
+    double* dW0 = dy + PB;
+    double* dhw = ctx->sm_buf + n_in;
+    double* dhc = dhw + n_hw;
+    int* dcount = reinterpret_cast<int*>(dhc + n_hc);
+    int* dflag = dcount + nruns;
+    HIPCHK(hipMemcpyAsync(ctx->sm_buf, h, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_descent_small, dim3((unsigned)nruns), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)dX, (int)PB,
+                       (const double*)dy, (int)n, (int)d, (const double*)dW0, sigmaY, (int)kernel, alpha, beta, (int)norm,
+                       (int)steprule, (int)max_its, dhw, dhc, dcount, dflag);
+    HIPCHK(hipGetLastError());
+    // the counts first: only the written part of the histories is copied back
+    HIPCHK(hipMemcpyAsync(h + n_in + n_hw + n_hc, dcount, n_ints * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int* hcount = reinterpret_cast<const int*>(h + n_in + n_hw + n_hc);
+    int maxc = 0;
+    for (int r = 0; r < nruns; ++r) {
+        count_out[r] = hcount[r];
+        flag_out[r] = hcount[nruns + r];
+        maxc = std::max(maxc, hcount[r]);
+    }
+    if (maxc == (int)H || nruns == 1) {
+        HIPCHK(hipMemcpyAsync(h + n_in, dhw, (n_hw + n_hc) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        for (int r = 0; r < nruns; ++r) {
+            HIPCHK(hipMemcpyAsync(h + n_in + (size_t)r * H * d, dhw + (size_t)r * H * d, (size_t)hcount[r] * d * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(h + n_in + n_hw + (size_t)r * H, dhc + (size_t)r * H, (size_t)hcount[r] * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < nruns; ++r) {
+        memcpy(w_hist_out + (size_t)r * H * d, h + n_in + (size_t)r * H * d, (size_t)count_out[r] * d * 8);
+        memcpy(c_hist_out + (size_t)r * H, h + n_in + n_hw + (size_t)r * H, (size_t)count_out[r] * 8);
+    }
+    return GPBO_OK;
+}
+
 int gpbo_set_timing(gpbo_ctx* ctx, int32_t enabled) {
     if (!ctx) return GPBO_ERR_BAD_ARG;
     ctx->timing_off = (enabled == 0);

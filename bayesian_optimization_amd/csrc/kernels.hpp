@@ -1774,6 +1774,204 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
 // LDS: W with pitch 129 (the packed copy of L lives in the same space while the inverse runs), scaled inputs, vectors.
 constexpr int SMALL_WP = PB + 1;
 constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 6 * PB + 4 * GRAD_D + 8;
+// The evaluation itself, for one setting: th (d length scales, any address space), sg; results to *out_nll, out_grad[0..d),
+// *out_info (written by thread 0 / threads < d).  All POTRF_THREADS threads must call it; lds: SMALL_LDS_DOUBLES doubles.
+// The caller separates two calls (and its own reads of the outputs) by a barrier.
+// The 16 x 16 threads hold the matrix as TS x TS register tiles, TS = 2 / 4 / 8 for n <= 32 / 64 / 128: with the 8 x 8
+// tiles alone a 36-point problem would keep 15 of the 256 threads busy in the covariance build and the gradient.
+struct SmallLds {
+    double *Wl, *xs, *dg, *yv, *zv, *al, *r1, *r2, *red, *sc;
+    __device__ __forceinline__ explicit SmallLds(double* lds) {
+        Wl = lds;                         // [128][129]; first the packed L
+        xs = Wl + PB * SMALL_WP;          // [GRAD_D][128] inputs / theta
+        dg = xs + GRAD_D * PB;            // [128] diag L
+        yv = dg + PB;
+        zv = yv + PB;
+        al = zv + PB;
+        r1 = al + PB;                     // [128] reduction scratch: y_i alpha_i
+        r2 = r1 + PB;                     // [128] reduction scratch: log diag L
+        red = r2 + PB;                    // [4][GRAD_D]
+        sc = red + 4 * GRAD_D;            // [0] y.alpha  [1] sum log diag L
+    }
+};
+
+// covariance tiles (identity pad beyond n) into the packed block, rows and columns < 16 TS
+template <int TS>
+__device__ __forceinline__ void lml_small_build(const SmallLds& m, int n, int d, double eps, int kernel) {
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+#pragma unroll
+    for (int rr = 0; rr < TS; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < TS; ++cc) {
+            const int r = tr * TS + rr, c = tc * TS + cc;
+            if (c > r) continue;
+            double v = 0.0;
+            if (r == c) {
+                v = (r < n) ? 1.0 + eps : 1.0;
+            } else if (r < n) {
+                double D = 0.0;
+                for (int t = 0; t < d; ++t) {
+                    const double df = m.xs[t * PB + r] - m.xs[t * PB + c];
+                    D += df * df;
+                }
+                v = kern_eval(D, kernel);
+            }
+            m.Wl[tri_off(r) + c] = v;
+        }
+}
+
+// everything after the inverse: W out of the packed block, z, alpha, the scalars, Kinv = W^T W tile by tile, gradient sums
+template <int TS>
+__device__ __forceinline__ void lml_small_finish(const SmallLds& m, int n, int d, const double* th, int kernel, int want_grad,
+                                                 int fail, double* out_nll, double* out_grad, int* out_info) {
+    constexpr int MS = 16 * TS;                // rows and columns covered by the register tiles
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    double* Wl = m.Wl;
+    const int nt = (n + TS - 1) / TS;          // tile columns that hold data; the rest of the block is the identity pad
+    double a[TS][TS];
+#pragma unroll
+    for (int rr = 0; rr < TS; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < TS; ++cc) {
+            const int r = tr * TS + rr, c = tc * TS + cc;
+            a[rr][cc] = (c <= r) ? Wl[tri_off(r) + (c <= r ? c : r)] : 0.0;
+        }
+    __syncthreads();                           // every read of the packed W is done
+#pragma unroll
+    for (int rr = 0; rr < TS; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < TS; ++cc) Wl[(tr * TS + rr) * SMALL_WP + tc * TS + cc] = a[rr][cc];
+    __syncthreads();
+    if (tid < PB) {                            // z = W y (row tid)
+        double z = 0.0;
+        if (tid < MS)
+            for (int c = 0; c <= min(tid, nt * TS - 1); ++c) z = fma(Wl[tid * SMALL_WP + c], m.yv[c], z);      // y is zero in the pad
+        m.zv[tid] = z;
+    }
+    __syncthreads();
+    if (tid < PB) {                            // alpha = W^T z (column tid)
+        double s = 0.0;
+        if (tid < MS)                          // beyond the register tiles the W space holds no matrix
+            for (int r = tid; r < nt * TS; ++r) s = fma(Wl[r * SMALL_WP + tid], m.zv[r], s);               // z is zero in the pad
+        m.al[tid] = s;
+        m.r1[tid] = m.yv[tid] * s;
+        m.r2[tid] = (tid < n) ? log(m.dg[tid]) : 0.0;
+    }
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (tid < o) {
+            m.r1[tid] += m.r1[tid + o];
+            m.r2[tid] += m.r2[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        m.sc[0] = m.r1[0];
+        m.sc[1] = m.r2[0];
+    }
+    __syncthreads();
+    const double ya = m.sc[0], sumlog = m.sc[1];
+    const double theta1 = ya / n;
+    const bool bad = fail >= 0;
+    if (tid == 0) {
+        const double nll = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(theta1) + sumlog;
+        *out_nll = bad ? NAN : nll;
+        *out_info = bad ? fail + 1 : 0;
+    }
+    if (!want_grad) return;
+    // Kinv tile (tr, tc), tr >= tc: sum over r >= TS tr of W[r][TS tr + rr] W[r][TS tc + cc] (W is zero above its diagonal)
+    const bool lower = tr >= tc;
+#pragma unroll
+    for (int rr = 0; rr < TS; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < TS; ++cc) a[rr][cc] = 0.0;
+    if (lower && tr < nt) {                    // pad rows of W are rows of the identity: they add nothing for j, k < n
+        for (int r = tr * TS; r < nt * TS; ++r) {
+            double wj[TS], wk[TS];
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                wj[t] = Wl[r * SMALL_WP + tr * TS + t];
+                wk[t] = Wl[r * SMALL_WP + tc * TS + t];
+            }
+#pragma unroll
+            for (int rr = 0; rr < TS; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < TS; ++cc) a[rr][cc] = fma(wj[rr], wk[cc], a[rr][cc]);
+        }
+        const double scale_c = (double)n / ya;
+        const double wgt = (tr == tc) ? 1.0 : 2.0;
+#pragma unroll
+        for (int rr = 0; rr < TS; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < TS; ++cc) {
+                const int j = tr * TS + rr, k = tc * TS + cc;
+                double c = 0.0;
+                if (j < n && k < n && j != k) {
+                    double D = 0.0;
+                    for (int t = 0; t < d; ++t) {
+                        const double df = m.xs[t * PB + j] - m.xs[t * PB + k];
+                        D += df * df;
+                    }
+                    c = wgt * (scale_c * m.al[j] * m.al[k] - a[rr][cc]) * kern_dfac(D, kernel);
+                }
+                a[rr][cc] = c;
+            }
+    }
+    for (int t = 0; t < d; ++t) {
+        double g = 0.0;
+        if (lower) {
+#pragma unroll
+            for (int rr = 0; rr < TS; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < TS; ++cc) {
+                    const double df = m.xs[t * PB + tr * TS + rr] - m.xs[t * PB + tc * TS + cc];
+                    g = fma(a[rr][cc], df * df, g);
+                }
+        }
+        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
+        if ((tid & 63) == 0) m.red[(tid >> 6) * GRAD_D + t] = g;
+    }
+    __syncthreads();
+    if (tid < d) {
+        const double sum = (m.red[tid] + m.red[GRAD_D + tid]) + (m.red[2 * GRAD_D + tid] + m.red[3 * GRAD_D + tid]);
+        out_grad[tid] = bad ? NAN : -0.5 * sum * (1.0 / th[tid]);
+    }
+}
+
+__device__ __forceinline__ void lml_small_body(double* __restrict__ lds, const double* __restrict__ Xraw, int xpitch,
+                                               const double* __restrict__ y, int n, int d, const double* th, double sg, int kernel,
+                                               int want_grad, double* out_nll, double* out_grad, int* out_info) {
+    const SmallLds m(lds);
+    const int tid = threadIdx.x;
+    const double eps = (sg == 0.0) ? 1e-15 * (double)n : sg * sg;
+    for (int idx = tid; idx < d * PB; idx += POTRF_THREADS) {
+        const int t = idx >> 7, i = idx & 127;
+        m.xs[idx] = (i < n) ? Xraw[(long)t * xpitch + i] * (1.0 / th[t]) : 0.0;
+    }
+    if (tid < PB) m.yv[tid] = (tid < n) ? y[tid] : 0.0;
+    __syncthreads();
+    // factor and inverse as in the diagonal-block kernel (register tile factorisation of the 16x16 tiles, everything
+    // else on MFMA), on the packed copy; the product buffer and the tile inverses live in the rest of the W space
+    __shared__ int fail_s;
+    double* Tbuf = m.Wl + POTRF_LDS_PACKED;
+    double* Wi8 = Tbuf + TRINV_T_DOUBLES;
+    static_assert(POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES <= PB * SMALL_WP, "scratch fits behind the packed block");
+    if (tid == 0) fail_s = -1;
+    if (n <= 32) lml_small_build<2>(m, n, d, eps, kernel);
+    else if (n <= 64) lml_small_build<4>(m, n, d, eps, kernel);
+    else lml_small_build<8>(m, n, d, eps, kernel);
+    __syncthreads();
+    const int ntl = (n + 15) >> 4;
+    potrf128_mfma(m.Wl, Wi8, &fail_s, ntl);
+    const int fail = fail_s;
+    if (tid < n) m.dg[tid] = m.Wl[tri_off(tid) + tid];
+    __syncthreads();                           // diag L is saved before the inverse overwrites it
+    trinv128_mfma(m.Wl, Wi8, Tbuf, ntl);
+    if (n <= 32) lml_small_finish<2>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
+    else if (n <= 64) lml_small_finish<4>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
+    else lml_small_finish<8>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
+}
+
 __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __restrict__ Xraw, int xpitch,
                                                              const double* __restrict__ y, int n, int d,
                                                              const double* __restrict__ thetas,
@@ -1781,169 +1979,111 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
                                                              double* __restrict__ out_nll, double* __restrict__ out_grad,
                                                              int* __restrict__ out_info) {
     __shared__ double lds[SMALL_LDS_DOUBLES];
-    double* Wl = lds;                         // [128][129]; first the packed L
-    double* xs = Wl + PB * SMALL_WP;          // [GRAD_D][128] inputs / theta
-    double* dg = xs + GRAD_D * PB;            // [128] diag L
-    double* yv = dg + PB;
-    double* zv = yv + PB;
-    double* al = zv + PB;
-    double* r1 = al + PB;                     // [128] reduction scratch: y_i alpha_i
-    double* r2 = r1 + PB;                     // [128] reduction scratch: log diag L
-    double* red = r2 + PB;                    // [4][GRAD_D]
-    double* sc = red + 4 * GRAD_D;            // [0] y.alpha  [1] sum log diag L
     const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int tr = tid >> 4, tc = tid & 15;
-    const double* th = thetas + (long)b * d;
-    const double sg = sigmas[b];
-    const double eps = (sg == 0.0) ? 1e-15 * (double)n : sg * sg;
-    for (int idx = tid; idx < d * PB; idx += POTRF_THREADS) {
-        const int t = idx >> 7, i = idx & 127;
-        xs[idx] = (i < n) ? Xraw[(long)t * xpitch + i] * (1.0 / th[t]) : 0.0;
-    }
-    if (tid < PB) yv[tid] = (tid < n) ? y[tid] : 0.0;
-    __syncthreads();
-    double a[8][8];
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            const int r = tr * 8 + rr, c = tc * 8 + cc;
-            double v = 0.0;
-            if (r == c) {
-                v = (r < n) ? 1.0 + eps : 1.0;
-            } else if (r < n && c < n && c < r) {
-                double D = 0.0;
-                for (int t = 0; t < d; ++t) {
-                    const double df = xs[t * PB + r] - xs[t * PB + c];
-                    D += df * df;
-                }
-                v = kern_eval(D, kernel);
-            }
-            a[rr][cc] = v;
-        }
-    const int nt = (n + 7) >> 3;               // tile columns that hold data; the rest of the block is the identity pad
-    // factor and inverse as in the diagonal-block kernel (register tile factorisation of the 16x16 tiles, everything
-    // else on MFMA), on the packed copy; the product buffer and the tile inverses live in the rest of the W space
-    __shared__ int fail_s;
-    double* Tbuf = Wl + POTRF_LDS_PACKED;
-    double* Wi8 = Tbuf + TRINV_T_DOUBLES;
-    static_assert(POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES <= PB * SMALL_WP, "scratch fits behind the packed block");
-    if (tid == 0) fail_s = -1;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            const int r = tr * 8 + rr, c = tc * 8 + cc;
-            if (c <= r) Wl[tri_off(r) + c] = a[rr][cc];
-        }
-    __syncthreads();
-    potrf128_mfma(Wl, Wi8, &fail_s, (n + 15) >> 4);
-    const int fail = fail_s;
-    if (tid < PB) dg[tid] = Wl[tri_off(tid) + tid];
-    __syncthreads();                           // diag L is saved before the inverse overwrites it
-    trinv128_mfma(Wl, Wi8, Tbuf, (n + 15) >> 4);
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            const int r = tr * 8 + rr, c = tc * 8 + cc;
-            a[rr][cc] = (c <= r) ? Wl[tri_off(r) + (c <= r ? c : r)] : 0.0;
-        }
-    __syncthreads();                           // every read of the packed W is done
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) Wl[(tr * 8 + rr) * SMALL_WP + tc * 8 + cc] = a[rr][cc];
-    __syncthreads();
-    if (tid < PB) {                            // z = W y (row tid)
-        double z = 0.0;
-        for (int c = 0; c <= min(tid, nt * 8 - 1); ++c) z = fma(Wl[tid * SMALL_WP + c], yv[c], z);      // y is zero in the pad
-        zv[tid] = z;
-    }
-    __syncthreads();
-    if (tid < PB) {                            // alpha = W^T z (column tid)
-        double s = 0.0;
-        for (int r = tid; r < nt * 8; ++r) s = fma(Wl[r * SMALL_WP + tid], zv[r], s);                   // z is zero in the pad
-        al[tid] = s;
-        r1[tid] = yv[tid] * s;
-        r2[tid] = (tid < n) ? log(dg[tid]) : 0.0;
-    }
-    __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) {
-        if (tid < o) {
-            r1[tid] += r1[tid + o];
-            r2[tid] += r2[tid + o];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        sc[0] = r1[0];
-        sc[1] = r2[0];
-    }
-    __syncthreads();
-    const double ya = sc[0], sumlog = sc[1];
-    const double theta1 = ya / n;
-    const bool bad = fail >= 0;
-    if (tid == 0) {
-        const double nll = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(theta1) + sumlog;
-        out_nll[b] = bad ? NAN : nll;
-        out_info[b] = bad ? fail + 1 : 0;
-    }
-    if (!want_grad) return;
-    // Kinv tile (tr, tc), tr >= tc: sum over r >= 8 tr of W[r][8 tr + rr] W[r][8 tc + cc] (W is zero above its diagonal)
-    const bool lower = tr >= tc;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) a[rr][cc] = 0.0;
-    if (lower && tr < nt) {                    // pad rows of W are rows of the identity: they add nothing for j, k < n
-        for (int r = tr * 8; r < nt * 8; ++r) {
-            double wj[8], wk[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                wj[t] = Wl[r * SMALL_WP + tr * 8 + t];
-                wk[t] = Wl[r * SMALL_WP + tc * 8 + t];
-            }
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-                for (int cc = 0; cc < 8; ++cc) a[rr][cc] = fma(wj[rr], wk[cc], a[rr][cc]);
-        }
-        const double scale_c = (double)n / ya;
-        const double wgt = (tr == tc) ? 1.0 : 2.0;
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-                const int j = tr * 8 + rr, k = tc * 8 + cc;
-                double D = 0.0;
-                for (int t = 0; t < d; ++t) {
-                    const double df = xs[t * PB + j] - xs[t * PB + k];
-                    D += df * df;
-                }
-                const double c = wgt * (scale_c * al[j] * al[k] - a[rr][cc]) * kern_dfac(D, kernel);
-                a[rr][cc] = (j < n && k < n && j != k) ? c : 0.0;
-            }
-    }
-    for (int t = 0; t < d; ++t) {
-        double g = 0.0;
-        if (lower) {
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-                for (int cc = 0; cc < 8; ++cc) {
-                    const double df = xs[t * PB + tr * 8 + rr] - xs[t * PB + tc * 8 + cc];
-                    g = fma(a[rr][cc], df * df, g);
-                }
-        }
-        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
-        if ((tid & 63) == 0) red[(tid >> 6) * GRAD_D + t] = g;
-    }
-    __syncthreads();
+    lml_small_body(lds, Xraw, xpitch, y, n, d, thetas + (long)b * d, sigmas[b], kernel, want_grad, out_nll + b,
+                   out_grad + (long)b * d, out_info + b);
+}
+
+// The reference's descent on -logL (conj_gradient_descent, BayesOpt_v4.ipynb:31-87, steprule other than 'backtrack') for
+// n <= 128, one workgroup per start, every iteration inside the kernel: a multi-start fit is ONE launch instead of one
+// launch, two copies and a host round trip per iteration.  Per iteration k = 1 .. max_its, as the reference:
+//   dstep = (1 - beta) dtemp + beta dir(grad),  dir = sign(grad) sqrt(d) (norm 0, 'component'), grad / |grad| (1, 'full'), grad (2)
+//   wn = w - alpha dstep;  steprule 1 ('diminishing'): alpha = 1 / k from the next iteration on
+//   evaluate at wn: not positive definite -> record (wn, inf) and stop; else accept (w, grad, cost, dtemp = dstep), record,
+//   and stop with exitflag 1 once |wn - w| < 1e-10.
+// hist_w [(r (max_its + 1) + i) d + t], hist_c [r (max_its + 1) + i]: the iterates of start r and their costs (inf where the
+// matrix was not positive definite), count[r] of them; flag[r] the exit flag.  Update arithmetic without fused
+// multiply-adds, operation for operation as NumPy evaluates the reference's expressions (the host loop of the larger sizes).
+__global__ __launch_bounds__(POTRF_THREADS) void k_descent_small(const double* __restrict__ Xraw, int xpitch,
+                                                                 const double* __restrict__ y, int n, int d,
+                                                                 const double* __restrict__ W0, double sg, int kernel, double alpha,
+                                                                 double beta, int norm, int steprule, int max_its,
+                                                                 double* __restrict__ hist_w, double* __restrict__ hist_c,
+                                                                 int* __restrict__ count, int* __restrict__ flag) {
+    __shared__ double lds[SMALL_LDS_DOUBLES];
+    __shared__ double w_s[GRAD_D], wn_s[GRAD_D], g_s[GRAD_D], gn_s[GRAD_D], dtemp_s[GRAD_D], dstep_s[GRAD_D];
+    __shared__ double nll_s, moved_s;
+    __shared__ int info_s, active_s;
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const long H = (long)max_its + 1;
     if (tid < d) {
-        const double sum = (red[tid] + red[GRAD_D + tid]) + (red[2 * GRAD_D + tid] + red[3 * GRAD_D + tid]);
-        out_grad[(long)b * d + tid] = bad ? NAN : -0.5 * sum * (1.0 / th[tid]);
+        w_s[tid] = W0[(long)r * d + tid];
+        dtemp_s[tid] = 0.0;
+    }
+    __syncthreads();
+    lml_small_body(lds, Xraw, xpitch, y, n, d, w_s, sg, kernel, 1, &nll_s, g_s, &info_s);
+    __syncthreads();
+    if (tid < d) hist_w[(r * H) * d + tid] = w_s[tid];
+    if (tid == 0) {
+        hist_c[r * H] = (info_s == 0) ? nll_s : INFINITY;
+        active_s = (info_s == 0);
+        count[r] = 1;
+        flag[r] = 0;
+    }
+    __syncthreads();
+    double alpha_r = alpha;
+    int cnt = 1;
+    for (int k = 1; k <= max_its && active_s; ++k) {
+        if (tid == 0) {
+#pragma clang fp contract(off)                      // no fused multiply-adds here: every product and sum rounds as NumPy's does
+            double gnorm = 0.0;
+            if (norm == 1) {
+                for (int t = 0; t < d; ++t) {
+                    const double sq = g_s[t] * g_s[t];
+                    gnorm = gnorm + sq;
+                }
+                gnorm = sqrt(gnorm);
+            }
+            const double sqd = sqrt((double)d), omb = 1.0 - beta;
+            double mv = 0.0;
+            for (int t = 0; t < d; ++t) {
+                const double g = g_s[t];
+                double dir;
+                if (norm == 0) {
+                    const double bs = beta * ((g != g) ? g : (double)((g > 0.0) - (g < 0.0)));
+                    dir = bs * sqd;
+                } else if (norm == 1) {
+                    const double gn = g / gnorm;
+                    dir = beta * gn;
+                } else {
+                    dir = beta * g;
+                }
+                const double mom = omb * dtemp_s[t];
+                const double ds = mom + dir;
+                const double stepv = alpha_r * ds;
+                const double wn = w_s[t] - stepv;
+                dstep_s[t] = ds;
+                wn_s[t] = wn;
+                const double df = wn - w_s[t];
+                const double sq = df * df;
+                mv = mv + sq;
+            }
+            moved_s = sqrt(mv);
+        }
+        if (steprule == 1) alpha_r = 1.0 / (double)k;
+        __syncthreads();
+        lml_small_body(lds, Xraw, xpitch, y, n, d, wn_s, sg, kernel, 1, &nll_s, gn_s, &info_s);
+        __syncthreads();
+        const bool ok = info_s == 0;
+        if (tid < d) {
+            hist_w[(r * H + cnt) * d + tid] = wn_s[tid];
+            if (ok) {
+                w_s[tid] = wn_s[tid];
+                g_s[tid] = gn_s[tid];
+                dtemp_s[tid] = dstep_s[tid];
+            }
+        }
+        if (tid == 0) {
+            hist_c[r * H + cnt] = ok ? nll_s : INFINITY;
+            count[r] = cnt + 1;
+            if (!ok) active_s = 0;
+            else if (moved_s < 1e-10) {
+                flag[r] = 1;
+                active_s = 0;
+            }
+        }
+        cnt += 1;
+        __syncthreads();
     }
 }
 

@@ -261,6 +261,27 @@ class GP:
                                              stat.ctypes.data_as(C.POINTER(C.c_int32))))
         return (nll, g, stat) if grad else (nll, stat)
 
+    def descent_small(self, xTrain, yTrain, W0, sigmaY, alpha, beta, norm, steprule, max_its, kernel=L.KERNEL_RBF):
+        """The reference's descent on -logL for every row of W0, to the end on the device (n <= 128, d <= 16, any step rule
+        but 'backtrack').  norm: 0 'component', 1 'full', 2 raw gradient; steprule: 0 constant, 1 'diminishing'.
+        Returns (w_hist (nruns, max_its+1, d), c_hist (nruns, max_its+1), count (nruns,), exitflag (nruns,)); only the first
+        count[r] entries of start r are meaningful."""
+        X = _f64(xTrain, 2)
+        y = _f64(np.asarray(yTrain).reshape(-1), 1)
+        W = _f64(W0, 2)
+        if W.shape[1] != X.shape[1] or y.shape[0] != X.shape[0]:
+            raise ValueError('W0 must be (nruns, d) and yTrain (n,)')
+        nruns, d, H = W.shape[0], W.shape[1], int(max_its) + 1
+        wh = np.zeros((nruns, H, d))
+        ch = np.full((nruns, H), np.nan)
+        cnt = np.zeros(nruns, dtype=np.int32)
+        flg = np.zeros(nruns, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self._check(self._lib.gpbo_descent_small(self._h, L.dptr(X), L.dptr(y), X.shape[0], d, L.dptr(W), nruns, float(sigmaY),
+                                                 int(kernel), float(alpha), float(beta), int(norm), int(steprule), int(max_its),
+                                                 L.dptr(wh), L.dptr(ch), cnt.ctypes.data_as(ip), flg.ctypes.data_as(ip)))
+        return wh, ch, cnt, flg
+
     def state_desc(self):
         sd = L.StateDesc()
         self._check(self._lib.gpbo_state_describe(self._h, C.byref(sd)))

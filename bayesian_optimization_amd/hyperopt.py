@@ -13,6 +13,8 @@ out of the whole multi-start loop).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .gp import GP
@@ -34,6 +36,15 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
     gp = _lml_gp(device)
     W = np.array(W0, dtype=np.float64, copy=True)
     nruns, d = W.shape
+    n = np.asarray(xTrain).shape[0]
+    if n <= 128 and d <= 16 and os.environ.get('GPBO_DESCENT_DEVICE', '1') != '0':
+        # small training sets: the whole descent of every start runs inside one kernel launch (same rule, same arithmetic)
+        wh, ch, cnt, flg = gp.descent_small(xTrain, yTrain, W, sigmaY, alpha, beta,
+                                            0 if norm == 'component' else (1 if norm == 'full' else 2),
+                                            1 if steprule == 'diminishing' else 0, int(max_its), kernel=kernel)
+        w_hist = [[wh[r, i].copy() for i in range(cnt[r])] for r in range(nruns)]
+        c_hist = [[float(ch[r, i]) for i in range(cnt[r])] for r in range(nruns)]
+        return w_hist, c_hist, flg.astype(int)
     tol = 1e-10
     sig = np.full(nruns, float(sigmaY))
     nll, grad, stat = gp.lml_batch(xTrain, yTrain, W, sig, kernel=kernel, grad=True)

@@ -203,6 +203,19 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
                    const double* thetas, const double* sigmas, int32_t B, int32_t kernel,
                    double* nll_out, double* grad_out, int32_t* status_out);
 
+/* conj_gradient_descent (BayesOpt_v4.ipynb:31-87) on -logL with the analytic gradient, for up to 128 training points and
+ * every step rule but 'backtrack': the nruns starts of hypopt (:167-178) run to the end on the device, one workgroup per
+ * start, one launch for the whole multi-start fit.  W0 (nruns,d) starting points; norm: 0 'component' (sign(grad) sqrt(d)),
+ * 1 'full' (grad / |grad|), 2 the raw gradient; steprule: 0 constant step alpha, 1 'diminishing' (alpha = 1/k).
+ * w_hist_out (nruns, max_its+1, d) and c_hist_out (nruns, max_its+1) receive weight_history and cost_history of every
+ * start (cost +inf where the covariance matrix is not positive definite: that start stops there), count_out (nruns) how
+ * many entries each start wrote, flag_out (nruns) the exit flag (1: the step fell below 1e-10).
+ * GPBO_ERR_BAD_ARG for n > 128 or d > 16: use gpbo_lml_batch and a host-side loop there. */
+int gpbo_descent_small(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, const double* W0,
+                       int32_t nruns, double sigmaY, int32_t kernel, double alpha, double beta, int32_t norm,
+                       int32_t steprule, int32_t max_its, double* w_hist_out, double* c_hist_out, int32_t* count_out,
+                       int32_t* flag_out);
+
 /* The factor gprfcn returns as L (the second one for the v4 variant, :147) as a dense
  * (n,n) lower-triangular matrix, and alpha as returned at :148,:152.  Either may be NULL. */
 int gpbo_get_factor(gpbo_ctx* ctx, double* L_out, double* alpha_out);

@@ -299,3 +299,28 @@ def test_singular_kriging_matrix_is_refused_where_the_reference_returns_garbage(
     assert float(g['cov']) < 0
     with pytest.raises(np.linalg.LinAlgError):
         nb.gpr_poly(g['xT'], g['yT'], g['xT'], g['theta'], 'gaussian', int(g['deg']))
+
+
+@pytest.mark.parametrize('norm,step', [('component', 'normal'), ('full', 'normal'), ('none', 'normal'), ('component', 'diminishing')])
+def test_device_resident_descent_equals_the_host_loop(monkeypatch, norm, step):
+    """n <= 128: the descent of all starts inside one kernel launch (gpbo_descent_small) against the host loop that calls
+    the likelihood sweep once per iteration: the same iterates, lengths and exit flags, bit for bit (the update rule is
+    evaluated without fused multiply-adds, as NumPy does), the same costs to the last bit or two."""
+    from bayesian_optimization_amd import notebook_api as nb
+    rng = np.random.default_rng(5)
+    for n, d in ((7, 1), (36, 2), (70, 3), (128, 2)):
+        X = rng.random((n, d))
+        y = np.sin(4 * X.sum(1)) + 0.05 * rng.standard_normal(n)
+        x0 = rng.random((6, d)) + 0.05
+        if norm != 'full':                             # (a zero gradient has no direction to normalise)
+            x0[0] = 1e-4                               # tiny length scale: K = I + jitter, gradient 0: the start stops at once
+        res = []
+        for dev in ('1', '0'):
+            monkeypatch.setenv('GPBO_DESCENT_DEVICE', dev)
+            res.append(nb.hypopt(6, 40, 0.01, 0.7, norm, step, X, y.reshape(-1, 1), None, 0.02, x0=x0.copy()))
+        (wa, ca, fa), (wb, cb, fb) = res
+        assert list(fa) == list(fb)
+        for r in range(6):
+            assert len(wa[r]) == len(wb[r]) and len(ca[r]) == len(cb[r])
+            assert np.array_equal(np.array(wa[r]), np.array(wb[r]))                          # the iterates: bit for bit
+            np.testing.assert_allclose(np.array(ca[r]), np.array(cb[r]), rtol=1e-13, atol=1e-12)      # -logL (a sum of terms of size ~n): two compilations of one routine
