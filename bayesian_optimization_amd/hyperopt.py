@@ -37,7 +37,7 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
     W = np.array(W0, dtype=np.float64, copy=True)
     nruns, d = W.shape
     n = np.asarray(xTrain).shape[0]
-    if n <= 128 and d <= 16 and os.environ.get('GPBO_DESCENT_DEVICE', '1') != '0':
+    if n <= 128 and d <= 16 and hasattr(gp, 'descent_small') and os.environ.get('GPBO_DESCENT_DEVICE', '1') != '0':
         # small training sets: the whole descent of every start runs inside one kernel launch (same rule, same arithmetic)
         wh, ch, cnt, flg = gp.descent_small(xTrain, yTrain, W, sigmaY, alpha, beta,
                                             0 if norm == 'component' else (1 if norm == 'full' else 2),
