@@ -1264,9 +1264,14 @@ int gpbo_descent_small(gpbo_ctx* ctx, const double* X, const double* y, int64_t 
     int* dcount = reinterpret_cast<int*>(dhc + n_hc);
     int* dflag = dcount + nruns;
     HIPCHK(hipMemcpyAsync(ctx->sm_buf, h, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_descent_small, dim3((unsigned)nruns), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)dX, (int)PB,
-                       (const double*)dy, (int)n, (int)d, (const double*)dW0, sigmaY, (int)kernel, alpha, beta, (int)norm,
-                       (int)steprule, (int)max_its, dhw, dhc, dcount, dflag);
+    if (n > 64)
+        hipLaunchKernelGGL(k_descent_small<true>, dim3((unsigned)nruns), dim3(SMALL_WIDE_THREADS), 0, ctx->stream, (const double*)dX,
+                           (int)PB, (const double*)dy, (int)n, (int)d, (const double*)dW0, sigmaY, (int)kernel, alpha, beta, (int)norm,
+                           (int)steprule, (int)max_its, dhw, dhc, dcount, dflag);
+    else
+        hipLaunchKernelGGL(k_descent_small<false>, dim3((unsigned)nruns), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)dX,
+                           (int)PB, (const double*)dy, (int)n, (int)d, (const double*)dW0, sigmaY, (int)kernel, alpha, beta, (int)norm,
+                           (int)steprule, (int)max_its, dhw, dhc, dcount, dflag);
     HIPCHK(hipGetLastError());
     // the counts first: only the written part of the histories is copied back
     HIPCHK(hipMemcpyAsync(h + n_in + n_hw + n_hc, dcount, n_ints * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1722,9 +1727,14 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         int* dinfo = reinterpret_cast<int*>(dgrad + (size_t)B * d);
         const auto t0 = std::chrono::steady_clock::now();
         HIPCHK(hipMemcpyAsync(ctx->sm_buf, h, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_lml_small, dim3((unsigned)B), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)dX, (int)PB,
-                           (const double*)dy, (int)n, (int)d, (const double*)dth, (const double*)dsg, (int)kernel, grad_out ? 1 : 0,
-                           dnll, dgrad, dinfo);
+        if (n > 64)
+            hipLaunchKernelGGL(k_lml_small<true>, dim3((unsigned)B), dim3(SMALL_WIDE_THREADS), 0, ctx->stream, (const double*)dX, (int)PB,
+                               (const double*)dy, (int)n, (int)d, (const double*)dth, (const double*)dsg, (int)kernel, grad_out ? 1 : 0,
+                               dnll, dgrad, dinfo);
+        else
+            hipLaunchKernelGGL(k_lml_small<false>, dim3((unsigned)B), dim3(POTRF_THREADS), 0, ctx->stream, (const double*)dX, (int)PB,
+                               (const double*)dy, (int)n, (int)d, (const double*)dth, (const double*)dsg, (int)kernel, grad_out ? 1 : 0,
+                               dnll, dgrad, dinfo);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h + n_in, dnll, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));

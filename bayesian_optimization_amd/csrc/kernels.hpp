@@ -1773,12 +1773,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
 //   g_t = -1/(2 theta_t) sum_{j != k} (n a_j a_k / (y.a) - Kinv_jk) q_t F_jk   (jacmlefun; F = K0 for RBF, kern_dfac)
 // LDS: W with pitch 129 (the packed copy of L lives in the same space while the inverse runs), scaled inputs, vectors.
 constexpr int SMALL_WP = PB + 1;
-constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 6 * PB + 4 * GRAD_D + 8;
+constexpr int SMALL_WIDE_THREADS = 1024;       // workgroup of the one-workgroup routines for 64 < n <= 128 (256 threads up to 64)
+constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 6 * PB + 16 * GRAD_D + 8;
 // The evaluation itself, for one setting: th (d length scales, any address space), sg; results to *out_nll, out_grad[0..d),
 // *out_info (written by thread 0 / threads < d).  All POTRF_THREADS threads must call it; lds: SMALL_LDS_DOUBLES doubles.
 // The caller separates two calls (and its own reads of the outputs) by a barrier.
-// The 16 x 16 threads hold the matrix as TS x TS register tiles, TS = 2 / 4 / 8 for n <= 32 / 64 / 128: with the 8 x 8
-// tiles alone a 36-point problem would keep 15 of the 256 threads busy in the covariance build and the gradient.
+// TG x TG threads hold the matrix as TS x TS register tiles: 16 x 16 threads with TS = 2 / 4 for n <= 32 / 64, 32 x 32
+// threads with TS = 4 for n <= 128 (WIDE: a 1024-thread workgroup, which also gives the factor and inverse routines their
+// 16 waves).  With 8 x 8 tiles on 256 threads a 36-point problem kept 15 threads busy in the covariance build and the
+// gradient, a 94-point one 144.
 struct SmallLds {
     double *Wl, *xs, *dg, *yv, *zv, *al, *r1, *r2, *red, *sc;
     __device__ __forceinline__ explicit SmallLds(double* lds) {
@@ -1790,15 +1793,15 @@ struct SmallLds {
         al = zv + PB;
         r1 = al + PB;                     // [128] reduction scratch: y_i alpha_i
         r2 = r1 + PB;                     // [128] reduction scratch: log diag L
-        red = r2 + PB;                    // [4][GRAD_D]
-        sc = red + 4 * GRAD_D;            // [0] y.alpha  [1] sum log diag L
+        red = r2 + PB;                    // [16][GRAD_D] per-wave gradient partials
+        sc = red + 16 * GRAD_D;           // [0] y.alpha  [1] sum log diag L
     }
 };
 
 // covariance tiles (identity pad beyond n) into the packed block, rows and columns < 16 TS
-template <int TS>
+template <int TS, int TG>
 __device__ __forceinline__ void lml_small_build(const SmallLds& m, int n, int d, double eps, int kernel) {
-    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    const int tid = threadIdx.x, tr = tid / TG, tc = tid % TG;
 #pragma unroll
     for (int rr = 0; rr < TS; ++rr)
 #pragma unroll
@@ -1821,11 +1824,12 @@ __device__ __forceinline__ void lml_small_build(const SmallLds& m, int n, int d,
 }
 
 // everything after the inverse: W out of the packed block, z, alpha, the scalars, Kinv = W^T W tile by tile, gradient sums
-template <int TS>
+template <int TS, int TG>
 __device__ __forceinline__ void lml_small_finish(const SmallLds& m, int n, int d, const double* th, int kernel, int want_grad,
                                                  int fail, double* out_nll, double* out_grad, int* out_info) {
-    constexpr int MS = 16 * TS;                // rows and columns covered by the register tiles
-    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    constexpr int MS = TG * TS;                // rows and columns covered by the register tiles
+    constexpr int NW = TG * TG / 64;           // waves
+    const int tid = threadIdx.x, tr = tid / TG, tc = tid % TG;
     double* Wl = m.Wl;
     const int nt = (n + TS - 1) / TS;          // tile columns that hold data; the rest of the block is the identity pad
     double a[TS][TS];
@@ -1933,18 +1937,22 @@ __device__ __forceinline__ void lml_small_finish(const SmallLds& m, int n, int d
     }
     __syncthreads();
     if (tid < d) {
-        const double sum = (m.red[tid] + m.red[GRAD_D + tid]) + (m.red[2 * GRAD_D + tid] + m.red[3 * GRAD_D + tid]);
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4)
+            sum += (m.red[w * GRAD_D + tid] + m.red[(w + 1) * GRAD_D + tid]) + (m.red[(w + 2) * GRAD_D + tid] + m.red[(w + 3) * GRAD_D + tid]);
         out_grad[tid] = bad ? NAN : -0.5 * sum * (1.0 / th[tid]);
     }
 }
 
+template <bool WIDE>
 __device__ __forceinline__ void lml_small_body(double* __restrict__ lds, const double* __restrict__ Xraw, int xpitch,
                                                const double* __restrict__ y, int n, int d, const double* th, double sg, int kernel,
                                                int want_grad, double* out_nll, double* out_grad, int* out_info) {
     const SmallLds m(lds);
     const int tid = threadIdx.x;
     const double eps = (sg == 0.0) ? 1e-15 * (double)n : sg * sg;
-    for (int idx = tid; idx < d * PB; idx += POTRF_THREADS) {
+    for (int idx = tid; idx < d * PB; idx += (WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS)) {
         const int t = idx >> 7, i = idx & 127;
         m.xs[idx] = (i < n) ? Xraw[(long)t * xpitch + i] * (1.0 / th[t]) : 0.0;
     }
@@ -1957,9 +1965,9 @@ __device__ __forceinline__ void lml_small_body(double* __restrict__ lds, const d
     double* Wi8 = Tbuf + TRINV_T_DOUBLES;
     static_assert(POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES <= PB * SMALL_WP, "scratch fits behind the packed block");
     if (tid == 0) fail_s = -1;
-    if (n <= 32) lml_small_build<2>(m, n, d, eps, kernel);
-    else if (n <= 64) lml_small_build<4>(m, n, d, eps, kernel);
-    else lml_small_build<8>(m, n, d, eps, kernel);
+    if (WIDE) lml_small_build<4, 32>(m, n, d, eps, kernel);
+    else if (n <= 32) lml_small_build<2, 16>(m, n, d, eps, kernel);
+    else lml_small_build<4, 16>(m, n, d, eps, kernel);
     __syncthreads();
     const int ntl = (n + 15) >> 4;
     potrf128_mfma(m.Wl, Wi8, &fail_s, ntl);
@@ -1967,12 +1975,13 @@ __device__ __forceinline__ void lml_small_body(double* __restrict__ lds, const d
     if (tid < n) m.dg[tid] = m.Wl[tri_off(tid) + tid];
     __syncthreads();                           // diag L is saved before the inverse overwrites it
     trinv128_mfma(m.Wl, Wi8, Tbuf, ntl);
-    if (n <= 32) lml_small_finish<2>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
-    else if (n <= 64) lml_small_finish<4>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
-    else lml_small_finish<8>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
+    if (WIDE) lml_small_finish<4, 32>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
+    else if (n <= 32) lml_small_finish<2, 16>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
+    else lml_small_finish<4, 16>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
 }
 
-__global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __restrict__ Xraw, int xpitch,
+template <bool WIDE>
+__global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_lml_small(const double* __restrict__ Xraw, int xpitch,
                                                              const double* __restrict__ y, int n, int d,
                                                              const double* __restrict__ thetas,
                                                              const double* __restrict__ sigmas, int kernel, int want_grad,
@@ -1980,7 +1989,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
                                                              int* __restrict__ out_info) {
     __shared__ double lds[SMALL_LDS_DOUBLES];
     const int b = blockIdx.x;
-    lml_small_body(lds, Xraw, xpitch, y, n, d, thetas + (long)b * d, sigmas[b], kernel, want_grad, out_nll + b,
+    lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, thetas + (long)b * d, sigmas[b], kernel, want_grad, out_nll + b,
                    out_grad + (long)b * d, out_info + b);
 }
 
@@ -1994,7 +2003,8 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_lml_small(const double* __res
 // hist_w [(r (max_its + 1) + i) d + t], hist_c [r (max_its + 1) + i]: the iterates of start r and their costs (inf where the
 // matrix was not positive definite), count[r] of them; flag[r] the exit flag.  Update arithmetic without fused
 // multiply-adds, operation for operation as NumPy evaluates the reference's expressions (the host loop of the larger sizes).
-__global__ __launch_bounds__(POTRF_THREADS) void k_descent_small(const double* __restrict__ Xraw, int xpitch,
+template <bool WIDE>
+__global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_descent_small(const double* __restrict__ Xraw, int xpitch,
                                                                  const double* __restrict__ y, int n, int d,
                                                                  const double* __restrict__ W0, double sg, int kernel, double alpha,
                                                                  double beta, int norm, int steprule, int max_its,
@@ -2011,7 +2021,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_descent_small(const double* _
         dtemp_s[tid] = 0.0;
     }
     __syncthreads();
-    lml_small_body(lds, Xraw, xpitch, y, n, d, w_s, sg, kernel, 1, &nll_s, g_s, &info_s);
+    lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, w_s, sg, kernel, 1, &nll_s, g_s, &info_s);
     __syncthreads();
     if (tid < d) hist_w[(r * H) * d + tid] = w_s[tid];
     if (tid == 0) {
@@ -2062,7 +2072,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_descent_small(const double* _
         }
         if (steprule == 1) alpha_r = 1.0 / (double)k;
         __syncthreads();
-        lml_small_body(lds, Xraw, xpitch, y, n, d, wn_s, sg, kernel, 1, &nll_s, gn_s, &info_s);
+        lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, wn_s, sg, kernel, 1, &nll_s, gn_s, &info_s);
         __syncthreads();
         const bool ok = info_s == 0;
         if (tid < d) {
