@@ -325,6 +325,12 @@ int chol_first_deferred(int nb, int batch) {
     return std::max(0, nb - 1 - trsm_rows_max / std::max(1, batch));      // block rows below the panel, over all slots
 }
 
+// The one-workgroup likelihood and descent routines use 1024 threads above this many training points, 256 up to it.
+int small_wide_min() {
+    static const int v = getenv("GPBO_SMALL_WIDE_MIN") ? atoi(getenv("GPBO_SMALL_WIDE_MIN")) : 32;
+    return v;
+}
+
 // Trailing updates with at most this many 128 x 128 tiles (over all slots) run on half tiles (k_syrk_update_half).
 long syrk_half_max() {
     static const long v = getenv("GPBO_SYRK_HALF_MAX") ? atol(getenv("GPBO_SYRK_HALF_MAX")) : 1024;
@@ -1264,7 +1270,7 @@ int gpbo_descent_small(gpbo_ctx* ctx, const double* X, const double* y, int64_t 
     int* dcount = reinterpret_cast<int*>(dhc + n_hc);
     int* dflag = dcount + nruns;
     HIPCHK(hipMemcpyAsync(ctx->sm_buf, h, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (n > 64)
+    if (n > small_wide_min())
         hipLaunchKernelGGL(k_descent_small<true>, dim3((unsigned)nruns), dim3(SMALL_WIDE_THREADS), 0, ctx->stream, (const double*)dX,
                            (int)PB, (const double*)dy, (int)n, (int)d, (const double*)dW0, sigmaY, (int)kernel, alpha, beta, (int)norm,
                            (int)steprule, (int)max_its, dhw, dhc, dcount, dflag);
@@ -1727,7 +1733,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         int* dinfo = reinterpret_cast<int*>(dgrad + (size_t)B * d);
         const auto t0 = std::chrono::steady_clock::now();
         HIPCHK(hipMemcpyAsync(ctx->sm_buf, h, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
-        if (n > 64)
+        if (n > small_wide_min())
             hipLaunchKernelGGL(k_lml_small<true>, dim3((unsigned)B), dim3(SMALL_WIDE_THREADS), 0, ctx->stream, (const double*)dX, (int)PB,
                                (const double*)dy, (int)n, (int)d, (const double*)dth, (const double*)dsg, (int)kernel, grad_out ? 1 : 0,
                                dnll, dgrad, dinfo);

@@ -1773,14 +1773,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double
 //   g_t = -1/(2 theta_t) sum_{j != k} (n a_j a_k / (y.a) - Kinv_jk) q_t F_jk   (jacmlefun; F = K0 for RBF, kern_dfac)
 // LDS: W with pitch 129 (the packed copy of L lives in the same space while the inverse runs), scaled inputs, vectors.
 constexpr int SMALL_WP = PB + 1;
-constexpr int SMALL_WIDE_THREADS = 1024;       // workgroup of the one-workgroup routines for 64 < n <= 128 (256 threads up to 64)
+constexpr int SMALL_WIDE_THREADS = 1024;       // workgroup of the one-workgroup routines for larger n (256 threads for small n)
 constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 6 * PB + 16 * GRAD_D + 8;
 // The evaluation itself, for one setting: th (d length scales, any address space), sg; results to *out_nll, out_grad[0..d),
 // *out_info (written by thread 0 / threads < d).  All POTRF_THREADS threads must call it; lds: SMALL_LDS_DOUBLES doubles.
 // The caller separates two calls (and its own reads of the outputs) by a barrier.
-// TG x TG threads hold the matrix as TS x TS register tiles: 16 x 16 threads with TS = 2 / 4 for n <= 32 / 64, 32 x 32
-// threads with TS = 4 for n <= 128 (WIDE: a 1024-thread workgroup, which also gives the factor and inverse routines their
-// 16 waves).  With 8 x 8 tiles on 256 threads a 36-point problem kept 15 threads busy in the covariance build and the
+// TG x TG threads hold the matrix as TS x TS register tiles: 16 x 16 threads with TS = 2 (n <= 32; TS = 4 up to 64 if the
+// caller asks for 256 threads there), 32 x 32 threads with TS = 2 / 4 for n <= 64 / 128 (WIDE: a 1024-thread workgroup,
+// which also gives the factor and inverse routines their 16 waves; the host uses it above 32 points).  With 8 x 8 tiles on 256 threads a 36-point problem kept 15 threads busy in the covariance build and the
 // gradient, a 94-point one 144.
 struct SmallLds {
     double *Wl, *xs, *dg, *yv, *zv, *al, *r1, *r2, *red, *sc;
@@ -1965,7 +1965,8 @@ __device__ __forceinline__ void lml_small_body(double* __restrict__ lds, const d
     double* Wi8 = Tbuf + TRINV_T_DOUBLES;
     static_assert(POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES <= PB * SMALL_WP, "scratch fits behind the packed block");
     if (tid == 0) fail_s = -1;
-    if (WIDE) lml_small_build<4, 32>(m, n, d, eps, kernel);
+    if (WIDE && n > 64) lml_small_build<4, 32>(m, n, d, eps, kernel);
+    else if (WIDE) lml_small_build<2, 32>(m, n, d, eps, kernel);
     else if (n <= 32) lml_small_build<2, 16>(m, n, d, eps, kernel);
     else lml_small_build<4, 16>(m, n, d, eps, kernel);
     __syncthreads();
@@ -1975,7 +1976,8 @@ __device__ __forceinline__ void lml_small_body(double* __restrict__ lds, const d
     if (tid < n) m.dg[tid] = m.Wl[tri_off(tid) + tid];
     __syncthreads();                           // diag L is saved before the inverse overwrites it
     trinv128_mfma(m.Wl, Wi8, Tbuf, ntl);
-    if (WIDE) lml_small_finish<4, 32>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
+    if (WIDE && n > 64) lml_small_finish<4, 32>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
+    else if (WIDE) lml_small_finish<2, 32>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
     else if (n <= 32) lml_small_finish<2, 16>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
     else lml_small_finish<4, 16>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
 }
