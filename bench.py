@@ -156,13 +156,20 @@ def sweep_block(a, config, gp, world, rank, backend, steps, warmup, with_cpu):
     m_local = hi - lo
 
     X, y, theta = synth.training_set(cfg)
-    fit_tm, cond_est, fit_wall = None, None, 0.0
+    fit_tm, cond_est, fit_wall, fit_first = None, None, 0.0, 0.0
     barrier()
     t0 = time.perf_counter()
     if rank == 0:
         gp.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
+        fit_wall = fit_first = time.perf_counter() - t0
+        if cfg['n'] <= 8192:
+            # the first call of a process also allocates the model's buffers and loads the kernels (milliseconds, which
+            # show at this size only): the per-phase times are those of a second call, the first call's wall time is
+            # kept beside them and stays the one the end-to-end figure uses
+            t1 = time.perf_counter()
+            gp.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
+            fit_wall = time.perf_counter() - t1
         fit_tm = gp.timings()
-        fit_wall = time.perf_counter() - t0
         cond_est = gp.cond_estimate()
     barrier()
     t0 = time.perf_counter()
@@ -230,15 +237,16 @@ def sweep_block(a, config, gp, world, rank, backend, steps, warmup, with_cpu):
     out['phase_rooflines'] = {'phases': [{'phase': k, 'bound': b, 'ms_per_step': t / steps * 1e3, 'frac': f} for k, b, t, f in ph],
                               'time_weighted_frac': sum(t * f for _, _, t, f in ph) / max(tsum, 1e-12)}
     nchol = max(fit_tm['chol_count'], 1)
-    out['fit'] = {'total_ms': fit_tm['fit_total_ms'], 'wall_ms': fit_wall * 1e3, 'cholesky_ms_each': fit_tm['chol_ms'] / nchol,
+    out['fit'] = {'total_ms': fit_tm['fit_total_ms'], 'wall_ms': fit_wall * 1e3, 'first_call_wall_ms': fit_first * 1e3,
+                  'cholesky_ms_each': fit_tm['chol_ms'] / nchol,
                   'cholesky_gflops': (n ** 3 / 3.0) / (fit_tm['chol_ms'] / nchol * 1e-3) / 1e9,
                   'inverse_ms': fit_tm['inverse_ms'], 'trsv_ms': fit_tm['trsv_ms'], 'kbuild_ms': fit_tm['kbuild_ms'],
                   'cond_estimate': cond_est}
     sweep_s = dt / steps
-    out['end_to_end'] = {'fit_ms': fit_wall * 1e3, 'broadcast_ms': bcast_s * 1e3, 'candidates_ms': cand_s * 1e3,
+    out['end_to_end'] = {'fit_ms': fit_first * 1e3, 'broadcast_ms': bcast_s * 1e3, 'candidates_ms': cand_s * 1e3,
                          'sweep_ms': sweep_s * 1e3,
                          'broadcast_bytes': 8.0 * ((-(-n // 128) * 128) ** 2) if world > 1 else 0.0,
-                         'candidates_per_sec_incl_fit_and_broadcast': m_total / (fit_wall + bcast_s + sweep_s)}
+                         'candidates_per_sec_incl_fit_and_broadcast': m_total / (fit_first + bcast_s + sweep_s)}
     if with_cpu:
         ns = 16384 if n <= 8192 else 2048
         Xs = synth.candidates(cfg, lo, lo + ns)
