@@ -306,7 +306,9 @@ int chol_group(int nb, int batch) {
                                                 // (n = 16384, 16 slots: 14.30 / 14.45 / 14.50 settings/s with 4 / 8 / 16)
     if (nb <= 56) return 1;        // small n: every launch is latency bound, one update per panel is the shortest chain
     if (nb <= 80) return 2;        // measured: n = 8192: 7.70 / 7.65 / 7.92 ms, n = 12288: 19.1 / 17.7 / 17.5 ms with 1 / 2 / 4
-    return nb >= 192 ? 8 : 4;      // large n: a longer K makes the bulk update more efficient
+    if (nb < 112) return 4;
+    return nb >= 192 ? 16 : 8;     // large n, bulk update in bands: n = 16384: 32.29 / 32.10 / 32.13 ms, 20480: 56.9 / 56.0 / 55.9,
+                                   // 32768: - / 195.3 / 194.5 (and 195.5 with 32) for 4 / 8 / 16
 }
 
 // Panel solve: one wave per 16 rows (k_trsm_rows) while every wave gets a SIMD of its own (8 waves per block row, 1024
@@ -473,9 +475,22 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
             if (T > 0 && tiles * ctx->batch <= syrk_half_max())
                 hipLaunchKernelGGL(k_syrk_update_half<true>, dim3((unsigned)(2 * tiles), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
                                    ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
-            else if (T > 0)
+            else if (T > 0) {
+                // tiles in bands of eight block rows (band_decode): at n = 32768 the group's panel (T x 128 rows x K columns,
+                // up to 500 MB) no longer stays in the 256 MB memory-side cache between the rows of tiles of the row-major
+                // order, which re-reads all of it once per row; a band of eight rows re-reads it once per band, and the
+                // eight tiles of a column meet in one XCD's L2.  GPBO_SYRK_BAND=0 selects the row-major order.
+                static const int band = getenv("GPBO_SYRK_BAND") ? atoi(getenv("GPBO_SYRK_BAND")) : 8;
+                if (band == 4)
+                    hipLaunchKernelGGL((k_syrk_update<true, 1, 4>), dim3((unsigned)tiles, 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
+                                       ctx->stream, A, ld, p0 + g, T, p0 * PB, g * PB, ctx->bs);
+                else if (band == 8)
+                    hipLaunchKernelGGL((k_syrk_update<true, 1, 8>), dim3((unsigned)tiles, 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
+                                       ctx->stream, A, ld, p0 + g, T, p0 * PB, g * PB, ctx->bs);
+                else
                 hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)tiles, 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
                                    ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
+            }
         }
     }
     const int first_deferred = chol_first_deferred(nb, ctx->batch);

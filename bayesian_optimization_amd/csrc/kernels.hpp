@@ -52,6 +52,48 @@ __device__ __forceinline__ void tri_decode(int t, int& i, int& j) {
     j = t - (int)((long)i * (i + 1) / 2);
 }
 
+// The same lower triangle of T block rows walked in bands of R rows: inside a band the tiles come in chunks of eight
+// columns, the R rows of a chunk one after the other, so that the R tiles that read the same column panel are eight
+// workgroup indices apart -- workgroups go round-robin over the eight XCDs, so they meet in one L2 while they run.
+// Band b (rows R b .. R b + R - 1) holds the R x R b rectangle left of the diagonal and its R x R tip; the rows of an
+// incomplete last band follow in row-major order.
+template <int R>
+__device__ __forceinline__ void band_decode(int t, int T, int& i, int& j) {
+    auto first = [](int b) { return R * R * (b * (b - 1) / 2) + b * (R * (R + 1) / 2); };
+    const int nfull = T / R;
+    int b = min((int)(__fsqrt_rn(2.0f * (float)t) * (1.0f / R)), nfull);
+    while (b < nfull && first(b + 1) <= t) ++b;
+    while (first(b) > t) --b;
+    int u = t - first(b);
+    if (b == nfull) {
+        i = R * b;
+        while (u >= i + 1) {
+            u -= i + 1;
+            ++i;
+        }
+        j = u;
+        return;
+    }
+    const int rect = R * R * b;
+    if (u < rect) {
+        const int full = (R * b) >> 3;
+        if (u < 8 * R * full) {
+            const int w = u % (8 * R);
+            i = R * b + (w >> 3);
+            j = 8 * (u / (8 * R)) + (w & 7);
+        } else {
+            const int cr = R * b - 8 * full, w = u - 8 * R * full;
+            i = R * b + w / cr;
+            j = 8 * full + w % cr;
+        }
+        return;
+    }
+    int ri, rj;
+    tri_decode(u - rect, ri, rj);
+    i = R * b + ri;
+    j = R * b + rj;
+}
+
 __device__ __forceinline__ double kern_eval(double D, int kernel) {
     if (kernel == 0) return exp(-0.5 * D);
     const double r = sqrt(D);
@@ -747,14 +789,17 @@ __global__ __launch_bounds__(1024) void k_trinv_diag(const double* __restrict__ 
 // read-modify-write of a tile of A is paid once per group instead of once per panel).
 // TRI: 1-D grid over the lower tiles of the square of blocks starting at b0 (ib = b0 + i, jb = b0 + j, j <= i).
 // !TRI: a rectangle of blocks, ib = b0 + blockIdx.y, jb = jb0 + blockIdx.x (every tile is computed).
-template <bool TRI>
+template <bool TRI, int MODE = 1, int BAND = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restrict__ A, long ld, int b0, int jb0, int kcol0,
                                                               int klen, BatchStride bs) {
     A += blockIdx.z * bs.mat;
     int ib, jb;
     if (TRI) {
         int i, j;
-        tri_decode(blockIdx.x, i, j);
+        if (BAND > 0)
+            band_decode<BAND>(blockIdx.x, jb0, i, j);       // jb0 carries the number of block rows here
+        else
+            tri_decode(blockIdx.x, i, j);
         ib = b0 + i;
         jb = b0 + j;
     } else {
@@ -775,7 +820,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restr
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)acc_row(ta, r) * ld + acc_col(tb)];
-    gemm_tile_128<true, true>(Pi, ld, Pj, ld, 0, klen, acc, lds);
+    gemm_tile_128<true, true, MODE>(Pi, ld, Pj, ld, 0, klen, acc, lds);
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
 #pragma unroll

@@ -189,3 +189,37 @@ np.savez(sys.argv[1], mu=mu, var=var, L=L, a=a, th1=gp.theta1, nll=gp.nll, idx=i
         assert rel(o2['L'], ref['L']) <= 1e-11 and rel(o2['a'], ref['a']) <= 1e-10
         assert rel(o2['mu'], ref['mu']) <= 1e-10 and rel(o2['var'], ref['var']) <= 1e-10 and int(o2['idx']) == int(ref['idx'])
         assert rel(o2['lml'], ref['lml']) <= 1e-12 and rel(o2['g'], ref['g']) <= 1e-8
+
+
+def test_tile_order_of_the_trailing_update_changes_no_bit(tmp_path):
+    """Large trailing updates walk their tiles in bands of eight block rows instead of row by row (cache reuse at
+    n = 32768).  Every tile is computed exactly once by the same arithmetic, so the factor must be bit-identical whatever
+    the order: forced onto a 21-block-row problem (bands of 8 and 4 with a rectangle, a tip and an incomplete last band)
+    and compared with the row-major order."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from bayesian_optimization_amd import GP, synth
+n, d = 2600, 3
+X = synth.uniform(41, n * d).reshape(n, d)
+y = np.sin(3 * X.sum(1)) + 0.1 * synth.normal(42, n)
+gp = GP(0)
+gp.fit(X, y, np.array([0.4, 0.5, 0.6]), 0.05)
+L, a = gp.factor()
+import hashlib
+np.savez(sys.argv[1], L=np.frombuffer(hashlib.sha256(np.ascontiguousarray(L).tobytes()).digest(), np.uint8), Lsum=np.abs(L).sum(),
+         a=a, th1=gp.theta1, nll=gp.nll)
+'''
+    outs = []
+    for k, band in enumerate(('0', '8', '4')):
+        path = str(tmp_path / ('band_%d.npz' % k))
+        env = dict(os.environ, GPBO_SYRK_BAND=band, GPBO_SYRK_HALF_MAX='0', GPBO_CHOL_GROUP='1')
+        proc = subprocess.run([sys.executable, '-c', code, path], env=env, cwd=ROOT, capture_output=True, text=True, timeout=150)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        outs.append(np.load(path))
+    assert np.isfinite(float(outs[0]['Lsum'])) and float(outs[0]['Lsum']) > 0 and float(outs[0]['th1']) > 0
+    for o in outs[1:]:
+        assert np.array_equal(o['L'], outs[0]['L']) and np.array_equal(o['a'], outs[0]['a'])
+        assert float(o['th1']) == float(outs[0]['th1']) and float(o['nll']) == float(outs[0]['nll'])
