@@ -1374,7 +1374,8 @@ __global__ __launch_bounds__(256) void k_ks_build(const double* __restrict__ Xs,
 // of a launch consists of one-k-block tiles.  Groups of 128 column blocks against one group of 256 (the whole chunk):
 // +2.4 % on two machines, -0.2 % on a third that ran both at the higher rate; narrower groups lose (48: -3 %, 8: -9 %);
 // alternating heavy and light row blocks loses 1-2 %.  An XCD-aware 8x8 super-tile order that also shares the Ks panels
-// measured 9 % slower (tiles marching through k in lockstep expose the miss latency).  Persistent workgroups that chain
+// measured 9 % slower (tiles marching through k in lockstep expose the miss latency); bands of 2 / 4 / 8 row blocks per
+// column block, dispatched together: -3 / -10 / -20 % at 32 row blocks, -0.3 / -1.2 / -2.8 % at 256.  Persistent workgroups that chain
 // their tiles (no prologue) and draw them from a counter: +0.7 % with one counter but 20 GB instead of 12 GB fetched per
 // launch (the row blocks of a column block no longer meet in one L2), -0.5 % with a counter per XCD; with a static
 // assignment -4 % (workgroups do not progress at equal rates).  The hardware dispatcher's order stays.
