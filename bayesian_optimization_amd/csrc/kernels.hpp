@@ -796,7 +796,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restr
     int ib, jb;
     if (TRI) {
         int i, j;
-        if (BAND > 0)
+        if constexpr (BAND > 0)
             band_decode<BAND>(blockIdx.x, jb0, i, j);       // jb0 carries the number of block rows here
         else
             tri_decode(blockIdx.x, i, j);
