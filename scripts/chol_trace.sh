@@ -19,7 +19,7 @@ rows = list(csv.DictReader(open(f)))
 with open(o + '.csv', 'w') as w:
     w.write('kernel,grid_x,grid_y,start_ns,dur_ns\n')
     for r in rows:
-        name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('gpbo::', '')
+        name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('gpbo::', '').replace(', ', ' ')
         w.write('%s,%s,%s,%s,%d\n' % (name, r['Grid_Size_X'], r['Grid_Size_Y'], r['Start_Timestamp'], int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
 print(len(rows), 'launches')
 PY
