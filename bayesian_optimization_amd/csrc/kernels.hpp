@@ -2061,7 +2061,7 @@ __global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_d
     __shared__ double lds[SMALL_LDS_DOUBLES];
     __shared__ double w_s[GRAD_D], wn_s[GRAD_D], g_s[GRAD_D], gn_s[GRAD_D], dtemp_s[GRAD_D], dstep_s[GRAD_D];
     __shared__ double nll_s, moved_s;
-    __shared__ int info_s, active_s;
+    __shared__ int info_s, active_s, unusable_s;
     const int tid = threadIdx.x, r = blockIdx.x;
     const long H = (long)max_its + 1;
     if (tid < d) {
@@ -2084,16 +2084,32 @@ __global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_d
     for (int k = 1; k <= max_its && active_s; ++k) {
         if (tid == 0) {
 #pragma clang fp contract(off)                      // no fused multiply-adds here: every product and sum rounds as NumPy's does
+            // sums of squares in the order of NumPy's add.reduce over a contiguous axis (what np.linalg.norm(., axis=1) runs):
+            // below eight terms one after the other; from eight on, eight running sums over blocks of eight, joined as
+            // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the leftover terms one by one
+            double sqv[GRAD_D];
+            auto numpy_sum = [&](int m) {
+                if (m < 8) {
+                    double acc = 0.0;
+                    for (int t = 0; t < m; ++t) acc = acc + sqv[t];
+                    return acc;
+                }
+                double r8[8];
+                for (int j = 0; j < 8; ++j) r8[j] = sqv[j];
+                int i = 8;
+                for (; i < m - (m % 8); i += 8)
+                    for (int j = 0; j < 8; ++j) r8[j] = r8[j] + sqv[i + j];
+                double acc = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+                for (; i < m; ++i) acc = acc + sqv[i];
+                return acc;
+            };
             double gnorm = 0.0;
             if (norm == 1) {
-                for (int t = 0; t < d; ++t) {
-                    const double sq = g_s[t] * g_s[t];
-                    gnorm = gnorm + sq;
-                }
-                gnorm = sqrt(gnorm);
+                for (int t = 0; t < d; ++t) sqv[t] = g_s[t] * g_s[t];
+                gnorm = sqrt(numpy_sum(d));
             }
             const double sqd = sqrt((double)d), omb = 1.0 - beta;
-            double mv = 0.0;
+            int unusable = 0;
             for (int t = 0; t < d; ++t) {
                 const double g = g_s[t];
                 double dir;
@@ -2113,14 +2129,18 @@ __global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_d
                 dstep_s[t] = ds;
                 wn_s[t] = wn;
                 const double df = wn - w_s[t];
-                const double sq = df * df;
-                mv = mv + sq;
+                sqv[t] = df * df;
+                unusable |= !(fabs(wn) < INFINITY) || wn == 0.0;
             }
-            moved_s = sqrt(mv);
+            moved_s = sqrt(numpy_sum(d));
+            unusable_s = unusable;
+            if (unusable) info_s = 1;
         }
         if (steprule == 1) alpha_r = 1.0 / (double)k;
         __syncthreads();
-        lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, wn_s, sg, kernel, 1, &nll_s, gn_s, &info_s);
+        // an iterate that is not a set of finite, non-zero length scales (0/0 from a zero gradient under the 'full' norm, an
+        // overflow) is not evaluated: the start ends there like one whose matrix is not positive definite
+        if (!unusable_s) lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, wn_s, sg, kernel, 1, &nll_s, gn_s, &info_s);
         __syncthreads();
         const bool ok = info_s == 0;
         if (tid < d) {

@@ -60,7 +60,8 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
         if norm == 'component':
             dstep = (1 - beta) * dtemp + beta * np.sign(grad) * np.sqrt(d)
         elif norm == 'full':
-            gn = grad / np.linalg.norm(grad, axis=1, keepdims=True)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                gn = grad / np.linalg.norm(grad, axis=1, keepdims=True)      # a zero gradient has no direction: NaN, handled below
             dstep = (1 - beta) * dtemp + beta * gn
         else:
             dstep = (1 - beta) * dtemp + beta * grad
@@ -69,7 +70,11 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
             alpha_r[:] = 1.0 / k
         Wn[~active] = W[~active]
         moved = np.linalg.norm(Wn - W, axis=1)
-        nll, gnew, stat = gp.lml_batch(xTrain, yTrain, Wn, sig, kernel=kernel, grad=True)
+        # an iterate that is not a set of length scales any more (NaN from a zero gradient under the 'full' norm, an
+        # overflow, an exact zero) cannot be evaluated: the start is frozen exactly like one whose K is not positive definite
+        unusable = ~np.all(np.isfinite(Wn) & (Wn != 0.0), axis=1)
+        nll, gnew, stat = gp.lml_batch(xTrain, yTrain, np.where(unusable[:, None], W, Wn), sig, kernel=kernel, grad=True)
+        stat = np.where(unusable, 1, stat)
         for r in range(nruns):
             if not active[r]:
                 continue
