@@ -8,8 +8,8 @@ evaluated by gpbo_lml_batch instead of autograd's reverse pass, and all nruns st
 
 Step rules: 'diminishing', 'backtrack' (the reference's own variant of the sufficient-decrease test, restated literally:
 :62-71) and the constant step (any other string, as in the reference where 'normal' / 'standard' fall through to the else
-branch).  A start whose K stops being positive definite is frozen with cost +inf (the reference would raise LinAlgError
-out of the whole multi-start loop).
+branch).  A start whose K stops being positive definite, or whose next iterate is not a set of finite non-zero length
+scales any more, is frozen with cost +inf (the reference would raise LinAlgError out of the whole multi-start loop).
 """
 from __future__ import annotations
 

@@ -208,7 +208,8 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
  * start, one launch for the whole multi-start fit.  W0 (nruns,d) starting points; norm: 0 'component' (sign(grad) sqrt(d)),
  * 1 'full' (grad / |grad|), 2 the raw gradient; steprule: 0 constant step alpha, 1 'diminishing' (alpha = 1/k).
  * w_hist_out (nruns, max_its+1, d) and c_hist_out (nruns, max_its+1) receive weight_history and cost_history of every
- * start (cost +inf where the covariance matrix is not positive definite: that start stops there), count_out (nruns) how
+ * start (cost +inf where the covariance matrix is not positive definite or the iterate is no longer a set of finite
+ * non-zero length scales: that start stops there, the iterate is still recorded), count_out (nruns) how
  * many entries each start wrote, flag_out (nruns) the exit flag (1: the step fell below 1e-10).
  * GPBO_ERR_BAD_ARG for n > 128 or d > 16: use gpbo_lml_batch and a host-side loop there. */
 int gpbo_descent_small(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, const double* W0,
