@@ -142,5 +142,60 @@ for c in range(max(cases // 4, 4)):
         print('MISMATCH descent', dict(n=n, d=d, nruns=nruns, its=its, norm=norm, step=step, sY=sY), flush=True)
 os.environ.pop('GPBO_DESCENT_DEVICE', None)
 print('descent: cases %d  mismatches so far %d  worst %s  (%.0f s)' % (ran, bad, {k: '%.2e' % v for k, v in worst.items()}, time.time() - t0), flush=True)
+
+# ---- part 5: acquisition functions and the first-occurrence argmax on uploaded posteriors (zeros in the variance, exact ties)
+worst = dict(ei=0.0, ucb=0.0, pi=0.0)
+for c in range(cases):
+    m = int(rng.choice([1, 2, 255, 256, 257, 2047, 2048, 2049, 4096, 10000, 65537, 300001]))
+    mu = rng.standard_normal(m)
+    var = rng.random(m) ** 3
+    var[rng.random(m) < 0.05] = 0.0
+    kappa = float(rng.choice([0.0, 0.01, 0.5]))
+    dup = rng.integers(0, m, size=min(m, 5))
+    gp.set_posterior(mu, var)
+    for acq, name in ((bo.ACQ_EI, 'ei'), (bo.ACQ_UCB, 'ucb'), (bo.ACQ_PI, 'pi')):
+        mode = int(rng.choice([bo.INCUMBENT_MAX_MU, bo.INCUMBENT_GIVEN]))
+        inc = float(np.max(mu)) if mode == bo.INCUMBENT_MAX_MU else float(rng.standard_normal())
+        if name == 'ei':
+            ref = o.expected_improvement(mu.copy(), var, kappa, incumbent=inc)
+        elif name == 'ucb':
+            ref = o.ucb(mu, var, kappa)
+        else:
+            ref = o.probability_of_improvement(mu, inc, np.sqrt(var))
+        # copies of the best candidate at random places: the first of the equal maxima must win
+        ref = np.atleast_1d(ref)
+        best = int(np.nanargmax(ref)) if np.isfinite(ref).any() else 0
+        mu2, var2 = mu.copy(), var.copy()
+        mu2[dup], var2[dup] = mu[best], var[best]
+        if mode == bo.INCUMBENT_MAX_MU:
+            inc = float(np.max(mu2))
+        gp.set_posterior(mu2, var2)
+        idx, top = gp.acquire(acq, kappa, mode, inc)
+        vals = gp.read(mu=False, var=False, acq=True)
+        if name == 'ei':
+            ref = o.expected_improvement(mu2.copy(), var2, kappa, incumbent=inc)
+        elif name == 'ucb':
+            ref = o.ucb(mu2, var2, kappa)
+        else:
+            ref = o.probability_of_improvement(mu2, inc, np.sqrt(var2))
+        ref = np.atleast_1d(ref)
+        fin = np.isfinite(ref)
+        diff = np.abs(vals[fin] - ref[fin])
+        if name == 'ei':
+            # deep in the lower tail imp Phi(Z) and sigma phi(Z) cancel: what either side can deliver is bounded by the
+            # rounding of the two terms, not of their difference
+            sg2 = np.sqrt(var2[fin])
+            with np.errstate(divide='ignore', invalid='ignore'):
+                terms = np.nan_to_num(sg2 * np.exp(-0.5 * ((mu2[fin] - inc - kappa) / sg2) ** 2), nan=0.0, posinf=0.0)
+            diff = np.maximum(diff - 1e-14 * terms, 0.0)
+        e = float(np.max(diff)) / max(float(np.max(np.abs(ref[fin]))), 1e-300) if fin.any() else 0.0
+        worst[name] = max(worst[name], e)
+        nan_same = np.array_equal(np.isnan(vals), np.isnan(ref))
+        own = int(np.nanargmax(vals)) if np.isfinite(vals).any() else -1
+        ok = e <= 1e-12 and nan_same and (own < 0 or (idx == own and top == vals[own]))
+        if not ok:
+            bad += 1
+            print('MISMATCH acquisition', dict(m=m, acq=name, mode=mode, kappa=kappa), e, idx, own, flush=True)
+print('acquisition: cases %d x 3  mismatches so far %d  worst %s  (%.0f s)' % (cases, bad, {k: '%.2e' % v for k, v in worst.items()}, time.time() - t0), flush=True)
 print('total mismatches', bad)
 sys.exit(1 if bad else 0)
