@@ -615,8 +615,8 @@ int reduce_max(gpbo_ctx* ctx, const double* a, int64_t m, double* dst_dev) {
 
 int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     if (!ctx->fitted) BADARG("posterior: no fitted model");
-    if (ctx->m <= 0 || !ctx->Xs) BADARG("posterior: no candidates");
-    if (ctx->m != ctx->xs_rows) BADARG("posterior: the resident posterior was uploaded with gpbo_set_posterior; call gpbo_set_candidates first");
+    if (ctx->xs_rows <= 0 || !ctx->Xs) BADARG("posterior: no candidates");
+    ctx->m = ctx->xs_rows;       // a posterior uploaded with gpbo_set_posterior (any length) is replaced by the one of the resident candidates
     CHK(ensure_scratch(ctx));
     const bool keep_v = (ctx->variant == GPBO_VARIANT_SINGLE && ctx->reserve > 0 && ctx->have_factor);   // also after the last append
     if (keep_v) {
@@ -1038,7 +1038,8 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = round_up(n + (variant == GPBO_VARIANT_SINGLE ? ctx->reserve : 0), PB);
     CHK(ensure_model(ctx, n_pad, d, true));
-    if (d != ctx->d) ctx->m = ctx->xs_rows = 0;   // resident candidates have the old column count: dropped
+    if (d != ctx->d) ctx->xs_rows = 0;            // resident candidates have the old column count: dropped
+    ctx->m = ctx->xs_rows;                        // (an uploaded posterior of another length goes with the old model)
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->inc_valid = false;
@@ -1361,7 +1362,8 @@ int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int64_t n_pad_in, int32_t d, int3
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = n_pad_in ? n_pad_in : round_up(n, PB);   // the sender's padding (it may hold rows reserved for appends)
     if (n_pad != ctx->cap_pad) CHK(ensure_model(ctx, n_pad, d, false));
-    if (d != ctx->d) ctx->m = ctx->xs_rows = 0;
+    if (d != ctx->d) ctx->xs_rows = 0;
+    ctx->m = ctx->xs_rows;
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->have_factor = false;
@@ -1419,7 +1421,8 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_pad = round_up(n, PB);
     CHK(ensure_model(ctx, n_pad, d, true));
-    if (d != ctx->d) ctx->m = ctx->xs_rows = 0;
+    if (d != ctx->d) ctx->xs_rows = 0;
+    ctx->m = ctx->xs_rows;
     ctx->fitted = false;
     ctx->have_posterior = false;
     ctx->inc_valid = false;

@@ -34,6 +34,7 @@ class GP:
         self._h = h
         self.device = int(device)
         self.n = self.d = self.m = 0
+        self._xs_rows = 0        # candidate rows resident on the device (m is the length of the current posterior)
         self.theta1 = self.nll = float('nan')
 
     # ------------------------------------------------------------------ plumbing
@@ -89,7 +90,8 @@ class GP:
         self._check(self._lib.gpbo_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th),
                                        float(sigmaY), int(kernel), int(variant), C.byref(t1), C.byref(nll)))
         if X.shape[1] != self.d:
-            self.m = 0           # candidates stay resident across refits unless the column count changes
+            self._xs_rows = 0    # candidates stay resident across refits unless the column count changes
+        self.m = self._xs_rows
         self.n, self.d = X.shape
         self.theta1, self.nll = t1.value, nll.value
         return self
@@ -99,25 +101,26 @@ class GP:
         if Xs.shape[1] != self.d:
             raise ValueError('xTest has %d columns, the model %d' % (Xs.shape[1], self.d))
         self._check(self._lib.gpbo_set_candidates(self._h, Xs.ctypes.data_as(C.c_void_p), Xs.shape[0], 0))
-        self.m = Xs.shape[0]
+        self.m = self._xs_rows = Xs.shape[0]
         return self
 
     def set_candidates_device(self, dev_ptr: int, m: int):
         """Candidates already in HBM (e.g. a torch tensor's data_ptr()); copied device-to-device."""
         self._check(self._lib.gpbo_set_candidates(self._h, C.c_void_p(int(dev_ptr)), int(m), 1))
-        self.m = int(m)
+        self.m = self._xs_rows = int(m)
         return self
 
     def set_candidates_uniform(self, seed: int, row_offset: int, m: int):
         """Rows [row_offset, row_offset + m) of synth.uniform's candidate stream, generated in HBM."""
         self._check(self._lib.gpbo_set_candidates_uniform(self._h, int(seed), int(row_offset), int(m)))
-        self.m = int(m)
+        self.m = self._xs_rows = int(m)
         return self
 
     def posterior(self):
         """Mean/variance for the resident candidates (kept in HBM); returns max(mu)."""
         mm = C.c_double()
         self._check(self._lib.gpbo_posterior(self._h, C.byref(mm)))
+        self.m = self._xs_rows   # (an uploaded posterior of another length is replaced)
         return mm.value
 
     def acquire(self, acq=L.ACQ_EI, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0, tie_rtol=0.0):
@@ -159,7 +162,7 @@ class GP:
         idx, eim, mum = C.c_int64(), C.c_double(), C.c_double()
         self._check(self._lib.gpbo_predict_ei(self._h, L.dptr(Xs), m, float(kappa), int(incumbent_mode), float(incumbent),
                                               L.dptr(mu), L.dptr(var), L.dptr(ei), C.byref(idx), C.byref(eim), C.byref(mum)))
-        self.m = m
+        self.m = self._xs_rows = m
         return mu, var, ei, int(idx.value), eim.value, mum.value
 
     def kriging_fit(self, xT, yT, theta, deg):
@@ -172,8 +175,11 @@ class GP:
         nb, cov = C.c_int32(), C.c_double()
         self._check(self._lib.gpbo_kriging_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1],
                                                float(np.squeeze(theta)), int(deg), L.dptr(beta), C.byref(nb), C.byref(cov)))
+        if X.shape[1] != self.d:
+            self._xs_rows = 0    # as in fit(): resident candidates survive a refit with the same column count
+        self.m = self._xs_rows
         self.n, self.d = X.shape
-        self.theta1, self.nll, self.m = cov.value, float('nan'), 0
+        self.theta1, self.nll = cov.value, float('nan')
         return beta[:nb.value].copy(), cov.value
 
     def set_posterior(self, mu, var):
@@ -290,6 +296,9 @@ class GP:
     def state_alloc(self, n, d, kernel, variant, sigmaY, n_pad=0):
         """n_pad: the sender's padded size (StateDesc.n_pad); 0 = round_up(n, 128)."""
         self._check(self._lib.gpbo_state_alloc(self._h, int(n), int(n_pad), int(d), int(kernel), int(variant), float(sigmaY)))
+        if int(d) != self.d:
+            self._xs_rows = 0
+        self.m = self._xs_rows
         self.n, self.d = int(n), int(d)
 
     def state_commit(self, y_max):

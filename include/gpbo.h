@@ -176,8 +176,9 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
 
 /* Make host arrays (m,) the resident posterior, so gpbo_acquire can run expected_improvement
  * (BayesOpt_v4.ipynb:188-197) / acquisition (Gaussian_Process_Regression.ipynb:265-268) on any Mu, diag(Cov).
- * The resident candidates no longer describe this posterior: unless m equals their row count, gpbo_posterior and
- * gpbo_append return GPBO_ERR_BAD_ARG until gpbo_set_candidates is called again. */
+ * Only the posterior arrays are replaced: the resident candidates stay as they are, and the next gpbo_posterior (or a
+ * refit with the same column count followed by it) recomputes the posterior over exactly those candidates, whatever m
+ * was here.  gpbo_append returns GPBO_ERR_BAD_ARG until gpbo_posterior has run again. */
 int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64_t m);
 
 /* kernfcn_v2(distmat_v2(U,V), theta) (BayesOpt_v4.ipynb:100-105,119-124): the (p,q) covariance matrix

@@ -51,22 +51,32 @@ def test_likelihood_sweep_leaves_the_callers_model_alone_and_survives_reallocati
 
 
 def test_uploaded_posterior_does_not_pose_as_candidates(gp0):
+    """An uploaded (mu, var) pair of any length replaces the posterior arrays only: the resident candidates stay what they
+    were, posterior() recomputes over exactly them (never over rows the longer upload would suggest), and a refit with the
+    same column count keeps them too."""
     X, y = _data(150, 2, 21)
     gp0.fit(X, y, np.array([0.3, 0.4]), 0.05)
     Xs = o.splitmix64_uniform(8, 400).reshape(200, 2)
     gp0.set_candidates(Xs)
     gp0.posterior()
     mu, var = gp0.read()
-    big = 5000                                        # longer than the resident candidate set
-    gp0.set_posterior(np.linspace(0, 1, big), np.full(big, 0.25))
-    idx, best = gp0.acquire(bo.ACQ_UCB, 1.0)
-    assert idx == big - 1 and best == 1.0 + 0.5
+    for big in (5000, 200, 7):                        # longer than, as long as, shorter than the resident candidate set
+        gp0.set_posterior(np.linspace(0, 1, big), np.full(big, 0.25))
+        idx, best = gp0.acquire(bo.ACQ_UCB, 1.0)
+        assert idx == big - 1 and best == 1.0 + 0.5 and gp0.m == big
+        gp0.posterior()
+        mu2, var2 = gp0.read()
+        assert gp0.m == 200 and np.array_equal(mu, mu2) and np.array_equal(var, var2)
+    gp0.set_posterior(np.linspace(0, 1, 5000), np.full(5000, 0.25))
+    gp0.fit(X, y, np.array([0.3, 0.4]), 0.05)         # the uploaded posterior goes with the old model, the candidates stay
     with pytest.raises(ValueError):
-        gp0.posterior()                               # no candidates describe this posterior
-    gp0.set_candidates(Xs)
+        gp0.read()
     gp0.posterior()
-    mu2, var2 = gp0.read()
-    assert np.array_equal(mu, mu2) and np.array_equal(var, var2)
+    mu3, var3 = gp0.read()
+    assert np.array_equal(mu, mu3) and np.array_equal(var, var3)
+    gp0.fit(np.hstack([X, X[:, :1]]), y, np.array([0.3, 0.4, 0.5]), 0.05)      # another column count: the candidates are dropped
+    with pytest.raises(ValueError):
+        gp0.posterior()
 
 
 def test_model_padded_for_appends_hands_over_with_its_padding(gp0):
