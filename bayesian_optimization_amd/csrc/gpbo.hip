@@ -100,6 +100,7 @@ struct gpbo_ctx {
     double *acq_pv = nullptr, *bmax = nullptr;   // per-workgroup partials: fused acquisition/argmax, max(mu) of the append sweep
     long* acq_pi = nullptr;
     bool have_posterior = false;
+    bool have_acq = false;      // acq holds the acquisition values of the current posterior
 
     // chunk scratch
     int64_t chunk_req = 0, chunk = 0, scratch_npad = 0;
@@ -720,6 +721,7 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     ctx->tm.finalize_ms = ms_acc[T_FIN];
     ctx->tm.trmm_flops = (double)ctx->n * (double)ctx->n * (double)ctx->m;
     ctx->have_posterior = true;
+    ctx->have_acq = false;
     ctx->inc_valid = keep_v;
     if (mu_max_out) *mu_max_out = mu_max;
     return GPBO_OK;
@@ -818,6 +820,7 @@ int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incum
     hipLaunchKernelGGL(k_argmax_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->acq_pv, (const long*)ctx->acq_pi,
                        (long)blocks, ctx->red_v2, ctx->red_i2);
     HIPCHK(hipGetLastError());
+    ctx->have_acq = store;       // (not stored: the array still holds the values of an earlier posterior)
     return GPBO_OK;
 }
 
@@ -854,6 +857,8 @@ int append_finish(gpbo_ctx* ctx, const StepResult& r, double* mu_max_out) {
         ctx->info = r.info;
         ctx->fitted = false;     // the factor row that was written is not usable
         ctx->inc_valid = false;
+        ctx->have_posterior = false;
+        ctx->have_acq = false;
         ctx->err = "append: enlarged matrix is not positive definite";
         return GPBO_ERR_NOT_PD;
     }
@@ -868,6 +873,7 @@ int append_finish(gpbo_ctx* ctx, const StepResult& r, double* mu_max_out) {
 
 int append_impl(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max_out) {
     CHK(append_check(ctx, x_new));
+    ctx->have_acq = false;       // the posterior changes under the stored acquisition values
     timing_begin(ctx);
     CHK(append_enqueue(ctx, x_new, y_new));
     StepResult r{};
@@ -891,7 +897,8 @@ int acquire_impl(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumben
 }
 
 // append + the acquisition over the updated posterior, one synchronisation.  The acquisition array is not stored
-// (gpbo_read(acq) after this call sees the values of the last gpbo_acquire).
+// (gpbo_read(acq) and gpbo_first_at_least are refused until the next gpbo_acquire: the values they would see are those of
+// an earlier posterior).
 int append_acquire_impl(gpbo_ctx* ctx, const double* x_new, double y_new, int acq, double kappa, int mode, double incumbent,
                         double* mu_max_out, int64_t* argmax_out, double* best_out) {
     CHK(append_check(ctx, x_new));
@@ -933,6 +940,7 @@ int reserve_candidates(gpbo_ctx* ctx, int64_t m) {
     ctx->m = m;
     ctx->xs_rows = m;
     ctx->have_posterior = false;
+    ctx->have_acq = false;
     ctx->inc_valid = false;
     return GPBO_OK;
 }
@@ -1042,6 +1050,7 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     ctx->m = ctx->xs_rows;                        // (an uploaded posterior of another length goes with the old model)
     ctx->fitted = false;
     ctx->have_posterior = false;
+    ctx->have_acq = false;
     ctx->inc_valid = false;
     ctx->n = n;
     ctx->n_pad = n_pad;
@@ -1166,7 +1175,7 @@ int gpbo_acquire(gpbo_ctx* ctx, int32_t acq, double kappa, int32_t incumbent_mod
 
 int gpbo_first_at_least(gpbo_ctx* ctx, double threshold, int64_t* index_out) {
     if (!ctx || !index_out) return GPBO_ERR_BAD_ARG;
-    if (!ctx->have_posterior) BADARG("first_at_least: no acquisition values (call gpbo_acquire first)");
+    if (!ctx->have_posterior || !ctx->have_acq) BADARG("first_at_least: no acquisition values for the current posterior (call gpbo_acquire first)");
     HIPCHK(hipSetDevice(ctx->device));
     const int blocks = (int)std::min<int64_t>(1024, (ctx->m + 255) / 256);
     hipLaunchKernelGGL(k_first_ge_stage, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->acq, (const long*)nullptr,
@@ -1185,6 +1194,7 @@ int gpbo_read(gpbo_ctx* ctx, double* mu, double* var, double* acq, int64_t offse
     if (!ctx) return GPBO_ERR_BAD_ARG;
     if (offset < 0 || count < 0 || offset + count > ctx->m) BADARG("read: range outside the candidate set");
     if (!ctx->have_posterior) BADARG("read: no posterior");
+    if (acq && !ctx->have_acq) BADARG("read: no acquisition values for the current posterior (call gpbo_acquire first)");
     HIPCHK(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)count * sizeof(double);
     if (mu) HIPCHK(hipMemcpyAsync(mu, ctx->mu + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1366,6 +1376,7 @@ int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int64_t n_pad_in, int32_t d, int3
     ctx->m = ctx->xs_rows;
     ctx->fitted = false;
     ctx->have_posterior = false;
+    ctx->have_acq = false;
     ctx->have_factor = false;
     ctx->n = n;
     ctx->n_pad = n_pad;
@@ -1425,6 +1436,7 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
     ctx->m = ctx->xs_rows;
     ctx->fitted = false;
     ctx->have_posterior = false;
+    ctx->have_acq = false;
     ctx->inc_valid = false;
     ctx->n = n;
     ctx->n_pad = n_pad;
@@ -1605,6 +1617,7 @@ int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64
     CHK(reduce_max(ctx, ctx->mu, m, ctx->inc_dev + 1));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_posterior = true;
+    ctx->have_acq = false;
     return GPBO_OK;
 }
 
@@ -1896,6 +1909,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         c->lookahead = (lanes == 1) && !use_graph;   // several lanes already overlap each other's panel work
         c->fitted = false;                           // the model buffers are work space here
         c->have_posterior = false;
+        c->have_acq = false;
         c->have_factor = false;
         c->inc_valid = false;
         c->n = n;

@@ -143,7 +143,8 @@ int gpbo_acquire_static(int32_t device, void* stream, const double* mu_dev, cons
                         int32_t acq, double kappa, int32_t incumbent_mode, double incumbent, double* acq_out_dev,
                         int64_t* argmax_out, double* best_out, double* mu_max_out);
 
-/* Copy count results starting at candidate offset to host; any pointer may be NULL. */
+/* Copy count results starting at candidate offset to host; any pointer may be NULL.  acq: the values the last gpbo_acquire
+ * stored; GPBO_ERR_BAD_ARG if the posterior has changed since (new candidates, model, appended point, uploaded posterior). */
 int gpbo_read(gpbo_ctx* ctx, double* mu, double* var, double* acq, int64_t offset, int64_t count);
 
 /* One call = set_candidates + posterior + acquire + read: the whole of
@@ -161,7 +162,8 @@ int gpbo_append(gpbo_ctx* ctx, const double* x_new, double y_new, double* mu_max
 
 /* One iteration of the frozen-theta loop in one call and one host synchronisation: gpbo_append(x_new, y_new) followed by
  * gpbo_acquire over the updated posterior (the body of BayesOpt_v4.ipynb:645-655 for the point picked last time and the
- * pick of the next one).  Same results, bit for bit, as the two calls; the acquisition array itself is not stored. */
+ * pick of the next one).  Same results, bit for bit, as the two calls; the acquisition array itself is not stored:
+ * gpbo_read with an acq pointer and gpbo_first_at_least return GPBO_ERR_BAD_ARG until the next gpbo_acquire. */
 int gpbo_append_acquire(gpbo_ctx* ctx, const double* x_new, double y_new, int32_t acq, double kappa, int32_t incumbent_mode,
                         double incumbent, double* mu_max_out, int64_t* argmax_out, double* best_out);
 

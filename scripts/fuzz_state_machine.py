@@ -42,7 +42,7 @@ for seq in range(seqs):
     gp.reserve_appends(S['reserve'])
     for step in range(steps):
         op = str(rng.choice(['fit', 'fit', 'kriging', 'cands', 'cands', 'posterior', 'posterior', 'posterior', 'acquire', 'append', 'append', 'append',
-                             'upload', 'lml', 'reserve', 'read', 'chunk', 'predict']))
+                             'upload', 'lml', 'reserve', 'read', 'readacq', 'chunk', 'predict']))
         counts[op] = counts.get(op, 0) + 1
         try:
             if op == 'fit':
@@ -126,6 +126,7 @@ for seq in range(seqs):
                 elif np.isfinite(vals).any() and (idx != int(np.nanargmax(vals)) or top != vals[idx]):
                     report(seq, step, op, 'argmax %d vs own first maximum %d' % (idx, int(np.nanargmax(vals))))
                 S['acq'] = True
+                S['acqvals'] = vals.copy()
             elif op == 'append':
                 can = S['kind'] == 'gp' and S['variant'] == bo.VARIANT_SINGLE and S['inc'] and S['left'] > 0 and S['post'] == 'model'
                 x_new = rng.random(S['d'] if S['d'] else 2); y_new = float(rng.standard_normal())
@@ -178,6 +179,23 @@ for seq in range(seqs):
                 mu, var = gp.read()
                 if len(mu) != len(S['mu']) or rel(mu, S['mu']) > 1e-8:
                     report(seq, step, op, 'stale or wrong posterior: %d values, expected %d' % (len(mu), len(S['mu'])))
+            elif op == 'readacq':
+                if S['post'] is not None and S['acq']:
+                    vals = np.atleast_1d(gp.read(mu=False, var=False, acq=True))
+                    if len(vals) != len(S['mu']) or not np.array_equal(vals, S['acqvals'], equal_nan=True):
+                        report(seq, step, op, 'stored acquisition values changed')
+                else:
+                    try:
+                        gp.read(mu=False, var=False, acq=True)
+                        if gp.m > 0:
+                            report(seq, step, op, 'returned acquisition values that belong to no current posterior')
+                    except REFUSE:
+                        pass
+                    try:
+                        gp.first_at_least(0.0)
+                        report(seq, step, op, 'first_at_least worked on stale acquisition values')
+                    except REFUSE:
+                        pass
             elif op == 'chunk':
                 gp.set_chunk(int(rng.choice([0, 256, 1024])))
             elif op == 'predict':
@@ -190,7 +208,7 @@ for seq in range(seqs):
                 mu_o, var_o = oracle_posterior(S)
                 if rel(mu, mu_o) > 1e-8 or float(np.max(np.abs(var - var_o))) > 1e-8 * max(float(np.max(np.abs(var_o))), 1e-300) or idx != int(np.argmax(ei)):
                     report(seq, step, op, 'mu %.2e' % rel(mu, mu_o))
-                S.update(post='model', mu=mu_o, var=var_o, inc=(S['variant'] == bo.VARIANT_SINGLE and S['reserve'] > 0), acq=True)
+                S.update(post='model', mu=mu_o, var=var_o, inc=(S['variant'] == bo.VARIANT_SINGLE and S['reserve'] > 0), acq=True, acqvals=ei.copy())
         except REFUSE as e:
             report(seq, step, op, 'refused a valid call: %s (state kind %r d %r candidates %r posterior %r)'
                    % (e, S['kind'], S['d'], None if S['Xs'] is None else S['Xs'].shape, S['post']))

@@ -233,3 +233,35 @@ np.savez(sys.argv[1], L=np.frombuffer(hashlib.sha256(np.ascontiguousarray(L).tob
     for o in outs[1:]:
         assert np.array_equal(o['L'], outs[0]['L']) and np.array_equal(o['a'], outs[0]['a'])
         assert float(o['th1']) == float(outs[0]['th1']) and float(o['nll']) == float(outs[0]['nll'])
+
+
+def test_stored_acquisition_values_go_with_their_posterior(gp0):
+    """gpbo_read(acq) and gpbo_first_at_least hand out what the last gpbo_acquire stored; once the posterior has changed
+    (recomputed, uploaded, a point appended, append_acquire -- which stores nothing) they must refuse instead of
+    returning the values of the earlier posterior."""
+    X, y = _data(120, 2, 23)
+    Xs = o.splitmix64_uniform(9, 600).reshape(300, 2)
+    gp0.reserve_appends(2)
+    gp0.fit(X, y, np.array([0.3, 0.4]), 0.05, variant=bo.VARIANT_SINGLE)
+    gp0.set_candidates(Xs)
+    gp0.posterior()
+    with pytest.raises(ValueError):
+        gp0.read(mu=False, var=False, acq=True)
+    idx, best = gp0.acquire()
+    ei = gp0.read(mu=False, var=False, acq=True)
+    assert ei[idx] == best and gp0.first_at_least(best) == idx
+    gp0.append(Xs[idx], 0.3)
+    for call in (lambda: gp0.read(mu=False, var=False, acq=True), lambda: gp0.first_at_least(0.0)):
+        with pytest.raises(ValueError):
+            call()
+    gp0.acquire()
+    gp0.read(mu=False, var=False, acq=True)
+    gp0.append_acquire(Xs[0], 0.1)
+    with pytest.raises(ValueError):
+        gp0.read(mu=False, var=False, acq=True)
+    mu, var = gp0.read()                              # the posterior itself stays readable
+    assert np.all(np.isfinite(mu)) and np.all(var >= 0)
+    gp0.posterior()
+    with pytest.raises(ValueError):
+        gp0.first_at_least(0.0)
+    gp0.reserve_appends(0)
