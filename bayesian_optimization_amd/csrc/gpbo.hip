@@ -1260,7 +1260,7 @@ int gpbo_descent_small(gpbo_ctx* ctx, const double* X, const double* y, int64_t 
     if (n <= 0 || n > PB || d <= 0 || d > GRAD_D) BADARG("descent_small: need 1 <= n <= 128 and 1 <= d <= 16");
     if (nruns <= 0 || max_its < 0 || max_its > (1 << 24)) BADARG("descent_small: need nruns >= 1 and 0 <= max_its <= 2^24");
     if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN52) BADARG("descent_small: unknown kernel");
-    if (norm < 0 || norm > 2 || steprule < 0 || steprule > 1) BADARG("descent_small: unknown norm or step rule");
+    if (norm < 0 || norm > 2 || steprule < 0 || steprule > 2) BADARG("descent_small: unknown norm or step rule");
     if (!(sigmaY >= 0)) BADARG("descent_small: sigmaY must be >= 0");
     for (int64_t i = 0; i < (int64_t)nruns * d; ++i)
         if (!(W0[i] != 0.0) || !std::isfinite(W0[i])) BADARG("descent_small: starting points must be finite and non-zero");
@@ -1296,7 +1296,15 @@ int gpbo_descent_small(gpbo_ctx* ctx, const double* X, const double* y, int64_t 
     int* dcount = reinterpret_cast<int*>(dhc + n_hc);
     int* dflag = dcount + nruns;
     HIPCHK(hipMemcpyAsync(ctx->sm_buf, h, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (n > small_wide_min())
+    if (steprule == 2 && n > small_wide_min())
+        hipLaunchKernelGGL(k_descent_backtrack_small<true>, dim3((unsigned)nruns), dim3(SMALL_WIDE_THREADS), 0, ctx->stream,
+                           (const double*)dX, (int)PB, (const double*)dy, (int)n, (int)d, (const double*)dW0, sigmaY, (int)kernel, alpha,
+                           beta, (int)norm, (int)max_its, dhw, dhc, dcount, dflag);
+    else if (steprule == 2)
+        hipLaunchKernelGGL(k_descent_backtrack_small<false>, dim3((unsigned)nruns), dim3(POTRF_THREADS), 0, ctx->stream,
+                           (const double*)dX, (int)PB, (const double*)dy, (int)n, (int)d, (const double*)dW0, sigmaY, (int)kernel, alpha,
+                           beta, (int)norm, (int)max_its, dhw, dhc, dcount, dflag);
+    else if (n > small_wide_min())
         hipLaunchKernelGGL(k_descent_small<true>, dim3((unsigned)nruns), dim3(SMALL_WIDE_THREADS), 0, ctx->stream, (const double*)dX,
                            (int)PB, (const double*)dy, (int)n, (int)d, (const double*)dW0, sigmaY, (int)kernel, alpha, beta, (int)norm,
                            (int)steprule, (int)max_its, dhw, dhc, dcount, dflag);

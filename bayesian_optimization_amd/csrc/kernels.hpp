@@ -2165,6 +2165,204 @@ __global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_d
     }
 }
 
+// Sum of m <= GRAD_D terms in the order of NumPy's add.reduce over a contiguous axis: below eight terms one after the other;
+// from eight on, eight running sums over blocks of eight, joined as a tree, then the leftover terms one by one.
+__device__ __forceinline__ double numpy_order_sum(const double* v, int m) {
+#pragma clang fp contract(off)
+    if (m < 8) {
+        double acc = 0.0;
+        for (int t = 0; t < m; ++t) acc = acc + v[t];
+        return acc;
+    }
+    double r8[8];
+    for (int j = 0; j < 8; ++j) r8[j] = v[j];
+    int i = 8;
+    for (; i < m - (m % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r8[j] = r8[j] + v[i + j];
+    double acc = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+    for (; i < m; ++i) acc = acc + v[i];
+    return acc;
+}
+
+// The 'backtrack' step rule of the same descent (BayesOpt_v4.ipynb:62-71), one workgroup per start, every trial point
+// evaluated inside the kernel.  Per outer iteration, as the reference:
+//   wtemp = w;  w = w - alpha d;  h = g(wtemp) + grad(wtemp).(w - wtemp) + |w - wtemp|^2 / (2 alpha)
+//   while g(w) > h (at most 200 rounds):  alpha *= 0.8;  w = w - alpha d;  h = (the same expression: old wtemp, new alpha);  wtemp = w
+//   w = w - alpha d            (one more step after the loop; alpha stays shrunk for the following iterations)
+// A trial point whose matrix is not positive definite, or that is no longer a set of finite non-zero length scales, ends the
+// start: the iterate after the closing step is recorded with cost +inf.  The walk is a three-phase state machine (0 first
+// trial, 1 a round of the shrinking loop, 2 the closing step) around ONE evaluation site; thread 0 keeps the books without
+// fused multiply-adds, in the order NumPy evaluates the expressions above over a batch of starts.
+template <bool WIDE>
+__global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_descent_backtrack_small(
+    const double* __restrict__ Xraw, int xpitch, const double* __restrict__ y, int n, int d, const double* __restrict__ W0, double sg,
+    int kernel, double alpha, double beta, int norm, int max_its, double* __restrict__ hist_w, double* __restrict__ hist_c,
+    int* __restrict__ count, int* __restrict__ flag) {
+    __shared__ double lds[SMALL_LDS_DOUBLES];
+    __shared__ double w_s[GRAD_D], wn_s[GRAD_D], g_s[GRAD_D], gn_s[GRAD_D], dtemp_s[GRAD_D], dstep_s[GRAD_D], wt_s[GRAD_D], gt_s[GRAD_D];
+    __shared__ double nll_s, cost_s, ft_s, h_s, alpha_s;
+    __shared__ int info_s, active_s, eval_s, phase_s, failed_s, rounds_s, k_s, cnt_s;
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const long H = (long)max_its + 1;
+    if (tid < d) {
+        w_s[tid] = W0[(long)r * d + tid];
+        dtemp_s[tid] = 0.0;
+    }
+    __syncthreads();
+    lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, w_s, sg, kernel, 1, &nll_s, g_s, &info_s);
+    __syncthreads();
+    if (tid < d) hist_w[(r * H) * d + tid] = w_s[tid];
+    if (tid == 0) {
+        cost_s = (info_s == 0) ? nll_s : INFINITY;
+        hist_c[r * H] = cost_s;
+        active_s = (info_s == 0) && max_its >= 1;
+        count[r] = 1;
+        flag[r] = 0;
+        alpha_s = alpha;
+        phase_s = 0;
+        k_s = 1;
+        cnt_s = 1;
+    }
+    __syncthreads();
+    while (active_s) {
+        if (tid == 0) {
+#pragma clang fp contract(off)
+            double sqv[GRAD_D];
+            const int phase = phase_s;
+            if (phase == 0) {
+                double gnorm = 0.0;
+                if (norm == 1) {
+                    for (int t = 0; t < d; ++t) sqv[t] = g_s[t] * g_s[t];
+                    gnorm = sqrt(numpy_order_sum(sqv, d));
+                }
+                const double sqd = sqrt((double)d), omb = 1.0 - beta;
+                for (int t = 0; t < d; ++t) {
+                    const double g = g_s[t];
+                    double dir;
+                    if (norm == 0) {
+                        const double bs = beta * ((g != g) ? g : (double)((g > 0.0) - (g < 0.0)));
+                        dir = bs * sqd;
+                    } else if (norm == 1) {
+                        const double gn = g / gnorm;
+                        dir = beta * gn;
+                    } else {
+                        dir = beta * g;
+                    }
+                    const double mom = omb * dtemp_s[t];
+                    dstep_s[t] = mom + dir;
+                    wt_s[t] = w_s[t];
+                    gt_s[t] = g_s[t];
+                    wn_s[t] = w_s[t];
+                }
+                ft_s = cost_s;
+                failed_s = 0;
+                rounds_s = 0;
+            } else if (phase == 1) {
+                alpha_s = alpha_s * 0.8;
+            }
+            const double a = alpha_s;
+            int unusable = 0;
+            for (int t = 0; t < d; ++t) {
+                const double stepv = a * dstep_s[t];
+                const double wn = wn_s[t] - stepv;
+                wn_s[t] = wn;
+                unusable |= !(fabs(wn) < INFINITY) || wn == 0.0;
+            }
+            if (phase == 1) {                   // the bound the coming evaluation is held against: old wtemp, its cost and gradient
+                for (int t = 0; t < d; ++t) {
+                    const double df = wn_s[t] - wt_s[t];
+                    sqv[t] = gt_s[t] * df;
+                }
+                const double s1 = numpy_order_sum(sqv, d);
+                for (int t = 0; t < d; ++t) {
+                    const double df = wn_s[t] - wt_s[t];
+                    sqv[t] = df * df;
+                }
+                const double s2 = numpy_order_sum(sqv, d);
+                const double two_a = 2.0 * a;
+                h_s = (ft_s + s1) + s2 / two_a;
+            }
+            const int skip = unusable || (phase == 2 && failed_s);
+            if (unusable) failed_s = 1;
+            eval_s = !skip;
+            info_s = skip ? 1 : 0;
+        }
+        __syncthreads();
+        // the gradient at the first trial point is never used (either the loop replaces it or the closing step moves on)
+        if (eval_s) lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, wn_s, sg, kernel, phase_s != 0, &nll_s, gn_s, &info_s);
+        __syncthreads();
+        if (tid == 0) {
+#pragma clang fp contract(off)
+            double sqv[GRAD_D];
+            const int phase = phase_s;
+            const bool bad = info_s != 0;
+            if (phase == 0) {
+                if (bad) {
+                    failed_s = 1;
+                    phase_s = 2;
+                } else {
+                    for (int t = 0; t < d; ++t) {
+                        const double df = wn_s[t] - wt_s[t];
+                        sqv[t] = gt_s[t] * df;
+                    }
+                    const double s1 = numpy_order_sum(sqv, d);
+                    for (int t = 0; t < d; ++t) {
+                        const double df = wn_s[t] - wt_s[t];
+                        sqv[t] = df * df;
+                    }
+                    const double s2 = numpy_order_sum(sqv, d);
+                    const double two_a = 2.0 * alpha_s;
+                    h_s = (ft_s + s1) + s2 / two_a;
+                    phase_s = (nll_s > h_s) ? 1 : 2;
+                }
+            } else if (phase == 1) {
+                rounds_s += 1;
+                if (bad) {
+                    failed_s = 1;
+                    phase_s = 2;
+                } else {
+                    for (int t = 0; t < d; ++t) {
+                        wt_s[t] = wn_s[t];
+                        gt_s[t] = gn_s[t];
+                    }
+                    ft_s = nll_s;
+                    phase_s = (nll_s > h_s && rounds_s < 200) ? 1 : 2;
+                }
+            } else {
+                const int cnt = cnt_s;
+                for (int t = 0; t < d; ++t) hist_w[(r * H + cnt) * d + t] = wn_s[t];
+                if (failed_s || bad) {
+                    hist_c[r * H + cnt] = INFINITY;
+                    active_s = 0;
+                } else {
+                    for (int t = 0; t < d; ++t) {
+                        const double df = wn_s[t] - w_s[t];
+                        sqv[t] = df * df;
+                    }
+                    const double moved = sqrt(numpy_order_sum(sqv, d));
+                    for (int t = 0; t < d; ++t) {
+                        w_s[t] = wn_s[t];
+                        g_s[t] = gn_s[t];
+                        dtemp_s[t] = dstep_s[t];
+                    }
+                    cost_s = nll_s;
+                    hist_c[r * H + cnt] = nll_s;
+                    if (moved < 1e-10) {
+                        flag[r] = 1;
+                        active_s = 0;
+                    }
+                }
+                count[r] = cnt + 1;
+                cnt_s = cnt + 1;
+                k_s += 1;
+                if (k_s > max_its) active_s = 0;
+                phase_s = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Per-lane device slot of the likelihood sweep: everything that changes from one setting to the next reaches the
 // kernels through it, so the launch sequence of a setting has constant arguments and can be replayed from a graph.
 struct LmlSlot {

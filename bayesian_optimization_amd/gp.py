@@ -268,8 +268,8 @@ class GP:
         return (nll, g, stat) if grad else (nll, stat)
 
     def descent_small(self, xTrain, yTrain, W0, sigmaY, alpha, beta, norm, steprule, max_its, kernel=L.KERNEL_RBF):
-        """The reference's descent on -logL for every row of W0, to the end on the device (n <= 128, d <= 16, any step rule
-        but 'backtrack').  norm: 0 'component', 1 'full', 2 raw gradient; steprule: 0 constant, 1 'diminishing'.
+        """The reference's descent on -logL for every row of W0, to the end on the device (n <= 128, d <= 16).
+        norm: 0 'component', 1 'full', 2 raw gradient; steprule: 0 constant, 1 'diminishing', 2 'backtrack'.
         Returns (w_hist (nruns, max_its+1, d), c_hist (nruns, max_its+1), count (nruns,), exitflag (nruns,)); only the first
         count[r] entries of start r are meaningful."""
         X = _f64(xTrain, 2)

@@ -7,7 +7,7 @@ evaluated by gpbo_lml_batch instead of autograd's reverse pass, and all nruns st
 -logL + gradient call per iteration (the starts are the batch axis of the likelihood sweep).
 
 Step rules: 'diminishing', 'backtrack' (the reference's own variant of the sufficient-decrease test, restated literally:
-:62-71) and the constant step (any other string, as in the reference where 'normal' / 'standard' fall through to the else
+:62-71; at most 200 shrinking rounds per iteration) and the constant step (any other string, as in the reference where 'normal' / 'standard' fall through to the else
 branch).  A start whose K stops being positive definite, or whose next iterate is not a set of finite non-zero length
 scales any more, is frozen with cost +inf (the reference would raise LinAlgError out of the whole multi-start loop).
 """
@@ -31,8 +31,6 @@ def _lml_gp(device=0):
 def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, steprule, max_its, W0, device=0, kernel=0):
     """All rows of W0 (nruns, d) advance in lockstep.  Returns (weight_history, cost_history, exitflag):
     weight_history[r] is the list of iterates of start r, cost_history[r] the -logL at each of them."""
-    if steprule == 'backtrack':
-        return _backtrack_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, max_its, W0, device, kernel)
     gp = _lml_gp(device)
     W = np.array(W0, dtype=np.float64, copy=True)
     nruns, d = W.shape
@@ -41,10 +39,13 @@ def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, ste
         # small training sets: the whole descent of every start runs inside one kernel launch (same rule, same arithmetic)
         wh, ch, cnt, flg = gp.descent_small(xTrain, yTrain, W, sigmaY, alpha, beta,
                                             0 if norm == 'component' else (1 if norm == 'full' else 2),
-                                            1 if steprule == 'diminishing' else 0, int(max_its), kernel=kernel)
+                                            2 if steprule == 'backtrack' else (1 if steprule == 'diminishing' else 0),
+                                            int(max_its), kernel=kernel)
         w_hist = [[wh[r, i].copy() for i in range(cnt[r])] for r in range(nruns)]
         c_hist = [[float(ch[r, i]) for i in range(cnt[r])] for r in range(nruns)]
         return w_hist, c_hist, flg.astype(int)
+    if steprule == 'backtrack':
+        return _backtrack_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, max_its, W0, device, kernel)
     tol = 1e-10
     sig = np.full(nruns, float(sigmaY))
     nll, grad, stat = gp.lml_batch(xTrain, yTrain, W, sig, kernel=kernel, grad=True)
@@ -100,7 +101,9 @@ def _step_direction(norm, grad, dtemp, beta, d):
     if norm == 'component':
         return (1 - beta) * dtemp + beta * np.sign(grad) * np.sqrt(d)
     if norm == 'full':
-        return (1 - beta) * dtemp + beta * grad / np.linalg.norm(grad, axis=1, keepdims=True)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            gn = grad / np.linalg.norm(grad, axis=1, keepdims=True)      # normalised first, then weighted, as the reference (:53-54)
+        return (1 - beta) * dtemp + beta * gn
     return (1 - beta) * dtemp + beta * grad
 
 
@@ -120,6 +123,9 @@ def _backtrack_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, max_its, W0, d
         nll = np.full(nruns, np.inf)
         g = np.zeros((nruns, d))
         st = np.ones(nruns, dtype=np.int32)
+        # a trial point that is not a set of finite non-zero length scales cannot be evaluated: it counts as a failed one
+        rows = np.asarray(rows, dtype=int)
+        rows = rows[np.all(np.isfinite(P[rows]) & (P[rows] != 0.0), axis=1)] if len(rows) else rows
         if len(rows):
             a, b, c = gp.lml_batch(xTrain, yTrain, P[rows], sig[rows], kernel=kernel, grad=True)
             nll[rows] = np.where(c == 0, a, np.inf)
@@ -141,7 +147,8 @@ def _backtrack_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, max_its, W0, d
         Wt, ft, gt = W.copy(), cost.copy(), grad.copy()
         Wn = W - alpha_r[:, None] * dstep
         fn, gn, sn = evaluate(Wn, rows)
-        h = ft + np.sum(gt * (Wn - Wt), axis=1) + np.sum((Wn - Wt) ** 2, axis=1) / (2 * alpha_r)
+        with np.errstate(invalid='ignore', over='ignore'):           # rows that just failed carry inf / NaN and are not looked at
+            h = ft + np.sum(gt * (Wn - Wt), axis=1) + np.sum((Wn - Wt) ** 2, axis=1) / (2 * alpha_r)
         inner = active & (sn == 0) & (fn > h)
         failed = active & (sn != 0)
         rounds = 0
@@ -160,13 +167,14 @@ def _backtrack_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, max_its, W0, d
         good = active & ~failed
         f3, g3, s3 = evaluate(Wn, np.flatnonzero(good))
         failed |= good & (s3 != 0)
+        moved_all = np.linalg.norm(Wn - W, axis=1)
         for r in rows:
             if failed[r]:                          # left the positive-definite region: freeze at the last good point
                 active[r] = False
                 c_hist[r].append(np.inf)
                 w_hist[r].append(Wn[r].copy())
                 continue
-            moved = np.linalg.norm(Wn[r] - W[r])
+            moved = moved_all[r]
             W[r], cost[r], grad[r], dtemp[r] = Wn[r], f3[r], g3[r], dstep[r]
             w_hist[r].append(W[r].copy())
             c_hist[r].append(cost[r])

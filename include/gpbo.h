@@ -207,9 +207,11 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
                    double* nll_out, double* grad_out, int32_t* status_out);
 
 /* conj_gradient_descent (BayesOpt_v4.ipynb:31-87) on -logL with the analytic gradient, for up to 128 training points and
- * every step rule but 'backtrack': the nruns starts of hypopt (:167-178) run to the end on the device, one workgroup per
+ * every step rule: the nruns starts of hypopt (:167-178) run to the end on the device, one workgroup per
  * start, one launch for the whole multi-start fit.  W0 (nruns,d) starting points; norm: 0 'component' (sign(grad) sqrt(d)),
- * 1 'full' (grad / |grad|), 2 the raw gradient; steprule: 0 constant step alpha, 1 'diminishing' (alpha = 1/k).
+ * 1 'full' (grad / |grad|), 2 the raw gradient; steprule: 0 constant step alpha, 1 'diminishing' (alpha = 1/k),
+ * 2 'backtrack' (:62-71: the step shrinks by 0.8 while -logL at the trial point exceeds the quadratic bound, at most 200
+ * times per iteration; every trial point is evaluated inside the launch, one history entry per outer iteration).
  * w_hist_out (nruns, max_its+1, d) and c_hist_out (nruns, max_its+1) receive weight_history and cost_history of every
  * start (cost +inf where the covariance matrix is not positive definite or the iterate is no longer a set of finite
  * non-zero length scales: that start stops there, the iterate is still recorded), count_out (nruns) how

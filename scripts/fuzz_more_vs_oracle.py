@@ -115,7 +115,7 @@ for c in range(max(cases // 4, 4)):
     nruns = int(rng.choice([1, 3, 10]))
     its = int(rng.choice([1, 15, 60]))
     norm = str(rng.choice(['component', 'full', 'none']))
-    step = str(rng.choice(['normal', 'diminishing']))
+    step = str(rng.choice(['normal', 'diminishing', 'backtrack']))
     sY = float(rng.choice([0.0, 0.02, 0.2]))
     X = rng.random((n, d)); y = np.sin(4 * X.sum(1)) + 0.05 * rng.standard_normal(n)
     x0 = rng.random((nruns, d)) + 0.05

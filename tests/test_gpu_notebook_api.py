@@ -301,7 +301,8 @@ def test_singular_kriging_matrix_is_refused_where_the_reference_returns_garbage(
         nb.gpr_poly(g['xT'], g['yT'], g['xT'], g['theta'], 'gaussian', int(g['deg']))
 
 
-@pytest.mark.parametrize('norm,step', [('component', 'normal'), ('full', 'normal'), ('none', 'normal'), ('component', 'diminishing')])
+@pytest.mark.parametrize('norm,step', [('component', 'normal'), ('full', 'normal'), ('none', 'normal'), ('component', 'diminishing'),
+                                       ('component', 'backtrack'), ('full', 'backtrack'), ('none', 'backtrack')])
 def test_device_resident_descent_equals_the_host_loop(monkeypatch, norm, step):
     """n <= 128: the descent of all starts inside one kernel launch (gpbo_descent_small) against the host loop that calls
     the likelihood sweep once per iteration: the same iterates, lengths and exit flags, bit for bit (the update rule is
