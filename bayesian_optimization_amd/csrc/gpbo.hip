@@ -730,16 +730,25 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
 template <int D>
 void launch_sweep_t(gpbo_ctx* ctx) {
     // two candidates per thread when every row of V starts 16-byte aligned (hipMalloc aligns the base; pitch = m)
+    // the launch's first `extra` workgroups write the new row of W and the enlarged alpha (columns 0 .. n)
+    static const bool in_sweep = [] { const char* e = getenv("GPBO_APPEND_IN_SWEEP"); return !(e && e[0] == '0'); }();
+    const int extra = in_sweep ? (int)((ctx->n + 1 + 255) / 256) : 0;
+    if (!in_sweep)
+        hipLaunchKernelGGL(k_append_wrow_alpha, dim3((unsigned)((ctx->n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufW,
+                           (long)ctx->n_pad, (int)ctx->n, (const double*)ctx->lvec, (const double*)ctx->scal, (const double*)ctx->zfw,
+                           ctx->alpha1, ctx->alpha);
     if (ctx->m % 2 == 0)
-        hipLaunchKernelGGL((k_append_sweep<D, 2>), dim3((unsigned)((ctx->m / 2 + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((k_append_sweep<D, 2>), dim3((unsigned)((ctx->m / 2 + 255) / 256 + extra)), dim3(256), 0, ctx->stream,
                            (const double*)ctx->Xs, (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params,
                            (const double*)ctx->lvec, (const double*)ctx->scal, ctx->Vres, (long)ctx->m, (int)ctx->n, ctx->sres, ctx->mu,
-                           ctx->var, ctx->kernel, ctx->bmax);
+                           ctx->var, ctx->kernel, ctx->bmax, extra, ctx->bufW, (long)ctx->n_pad, (const double*)ctx->zfw, ctx->alpha1,
+                           ctx->alpha);
     else
-        hipLaunchKernelGGL((k_append_sweep<D, 1>), dim3((unsigned)((ctx->m + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((k_append_sweep<D, 1>), dim3((unsigned)((ctx->m + 255) / 256 + extra)), dim3(256), 0, ctx->stream,
                            (const double*)ctx->Xs, (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params,
                            (const double*)ctx->lvec, (const double*)ctx->scal, ctx->Vres, (long)ctx->m, (int)ctx->n, ctx->sres, ctx->mu,
-                           ctx->var, ctx->kernel, ctx->bmax);
+                           ctx->var, ctx->kernel, ctx->bmax, extra, ctx->bufW, (long)ctx->n_pad, (const double*)ctx->zfw, ctx->alpha1,
+                           ctx->alpha);
 }
 
 // ---- one BO-loop step in two halves: enqueue (launches only) and finish (one copy + one synchronisation), so that the
@@ -768,10 +777,6 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new) {
                        (const double*)ctx->kvec, ctx->lvec);
     hipLaunchKernelGGL(k_append_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->lvec, ctx->zfw, ctx->yv, n,
                        y_new, ctx->eps, ctx->scal, ctx->params, ctx->bufL, ctx->bufW, ld, ctx->info_dev);
-    hipLaunchKernelGGL(k_append_wrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufW, ld, n,
-                       (const double*)ctx->lvec, (const double*)ctx->scal);
-    hipLaunchKernelGGL(k_append_alpha, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const double*)ctx->bufW, ld, n + 1, (const double*)ctx->zfw, ctx->alpha1, ctx->alpha);
     {
         Scope sw(ctx, T_SWEEP);
         switch (ctx->d) {
@@ -796,7 +801,7 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new) {
     return GPBO_OK;
 }
 
-// acquisition + argmax stage 1 fused, stage 2; results stay in red_v2 / red_i2.  store: keep the acquisition array.
+// acquisition + argmax stage 1 fused; the per-workgroup results stay in acq_pv / acq_pi.  store: keep the acquisition array.
 int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumbent, bool store, bool inc_ready = false) {
     if (acq < 0 || acq > 2) BADARG("acquire: unknown acquisition");
     Scope s(ctx, T_ACQ);
@@ -817,8 +822,7 @@ int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incum
     else
         hipLaunchKernelGGL(k_acquire_argmax<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, (const double*)ctx->var,
                            (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi);
-    hipLaunchKernelGGL(k_argmax_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->acq_pv, (const long*)ctx->acq_pi,
-                       (long)blocks, ctx->red_v2, ctx->red_i2);
+    // (the last argmax stage, over the `blocks` per-workgroup results, runs inside the end-of-step launch: step_fetch)
     HIPCHK(hipGetLastError());
     ctx->have_acq = store;       // (not stored: the array still holds the values of an earlier posterior)
     return GPBO_OK;
@@ -833,10 +837,15 @@ struct StepResult {      // what one synchronisation brings back
 
 int step_fetch(gpbo_ctx* ctx, StepResult* r, bool want_append, bool want_acquire) {
     (void)want_append;
-    (void)want_acquire;
-    // one small kernel stores everything into the pinned result block; the synchronisation is the whole transfer
-    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->params, (const int*)ctx->info_dev,
-                       (const double*)(ctx->inc_dev + 1), (const double*)ctx->red_v2, (const long*)ctx->red_i2, ctx->res_dev);
+    // one small kernel stores everything into the pinned result block; the synchronisation is the whole transfer.  After an
+    // acquisition the same launch first finishes the argmax over the per-workgroup results.
+    if (want_acquire)
+        hipLaunchKernelGGL(k_argmax_step_end, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ctx->acq_pv, (const long*)ctx->acq_pi,
+                           (long)((ctx->m + ACQ_SPAN - 1) / ACQ_SPAN), (const double*)ctx->params, (const int*)ctx->info_dev,
+                           (const double*)(ctx->inc_dev + 1), ctx->res_dev);
+    else
+        hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->params, (const int*)ctx->info_dev,
+                           (const double*)(ctx->inc_dev + 1), (const double*)ctx->red_v2, (const long*)ctx->red_i2, ctx->res_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(r->par, ctx->res_host, sizeof(r->par));

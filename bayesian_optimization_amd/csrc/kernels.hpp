@@ -1578,6 +1578,50 @@ __device__ __forceinline__ bool better(double v, long i, double bv, long bi) {
     return (v > bv) || (v == bv && i < bi);
 }
 
+// The last stage of the argmax (over the per-workgroup results of k_acquire_argmax) and the end-of-step block in one
+// single-workgroup launch: res[10] / res[11] receive the winner, the rest as k_step_end.  Which of several equal values wins
+// is decided by the index alone, so the result does not depend on the shape of the reduction.
+__global__ __launch_bounds__(1024) void k_argmax_step_end(const double* __restrict__ pv, const long* __restrict__ pi, long m,
+                                                          const double* __restrict__ params, const int* __restrict__ info,
+                                                          const double* __restrict__ mu_max, double* __restrict__ res) {
+    __shared__ double rv[1024];
+    __shared__ long ri[1024];
+    const int tid = threadIdx.x;
+    double bv = -INFINITY;
+    long bi = INT64_MAX;
+    for (long i0 = tid; i0 < m; i0 += 4096) {
+        double v[4];
+        long g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * 1024;
+            v[u] = (i < m) ? pv[i] : -INFINITY;
+            g[u] = (i < m) ? pi[i] : INT64_MAX;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (better(v[u], g[u], bv, bi)) {
+                bv = v[u];
+                bi = g[u];
+            }
+    }
+    rv[tid] = bv;
+    ri[tid] = bi;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o && better(rv[tid + o], ri[tid + o], rv[tid], ri[tid])) {
+            rv[tid] = rv[tid + o];
+            ri[tid] = ri[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid < 8) res[tid] = params[tid];
+    if (tid == 8) res[8] = (double)*info;
+    if (tid == 9) res[9] = *mu_max;
+    if (tid == 10) res[10] = rv[0];
+    if (tid == 11) reinterpret_cast<long*>(res)[11] = ri[0];
+}
+
 __global__ __launch_bounds__(256) void k_argmax_stage(const double* __restrict__ a, const long* __restrict__ idx_in, long m,
                                                       double* __restrict__ out_v, long* __restrict__ out_i) {
     __shared__ double rv[256];
@@ -2520,25 +2564,38 @@ __global__ __launch_bounds__(256) void k_append_scalars(const double* __restrict
     }
 }
 
-// New row of W: W[n][j] = -(1/d_new) * sum_{i>=j} l_i W[i][j]  (thread per column, coalesced), j < n.
-__global__ __launch_bounds__(256) void k_append_wrow(double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
-                                                     const double* __restrict__ scal) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    double s = 0.0;
-    for (int i = j; i < n; ++i) s += lvec[i] * W[(long)i * ld + j];
-    W[(long)n * ld + j] = -s / scal[A_DNEW];
+// New row of W and the enlarged alpha, thread per column j <= n (n = size before the append):
+//   W[n][j] = -(1/d_new) * sum_{i=j..n-1} l_i W[i][j]  (j < n; W[n][n] is already in place),
+//   alpha1[j] = alpha[j] = sum_{i=j..n} W[i][j] z_i   (W^T z over the enlarged model; the mean of this variant uses alpha = alpha1).
+// Neither is read by the sweep over the candidates, so the first workgroup(s) of the sweep's launch run this routine
+// beside it instead of two launches of their own in front of it.
+__device__ __forceinline__ void append_wrow_alpha(int blk, double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
+                                                  const double* __restrict__ scal, const double* __restrict__ zfw,
+                                                  double* __restrict__ alpha1, double* __restrict__ alpha) {
+    const int j = blk * 256 + threadIdx.x;
+    if (j > n) return;
+    double a = 0.0, wn;
+    if (j < n) {
+        double s = 0.0;
+        for (int i = j; i < n; ++i) {
+            const double w = W[(long)i * ld + j];
+            s += lvec[i] * w;
+            a += w * zfw[i];
+        }
+        wn = -s / scal[A_DNEW];
+        W[(long)n * ld + j] = wn;
+    } else {
+        wn = W[(long)n * ld + n];
+    }
+    a += wn * zfw[n];
+    alpha1[j] = a;
+    alpha[j] = a;
 }
 
-// alpha1 = W^T z over the enlarged model (n1 rows); alpha (used for the mean) = alpha1 for this variant.
-__global__ __launch_bounds__(256) void k_append_alpha(const double* __restrict__ W, long ld, int n1, const double* __restrict__ zfw,
-                                                      double* __restrict__ alpha1, double* __restrict__ alpha) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n1) return;
-    double s = 0.0;
-    for (int i = j; i < n1; ++i) s += W[(long)i * ld + j] * zfw[i];
-    alpha1[j] = s;
-    alpha[j] = s;
+__global__ __launch_bounds__(256) void k_append_wrow_alpha(double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
+                                                           const double* __restrict__ scal, const double* __restrict__ zfw,
+                                                           double* __restrict__ alpha1, double* __restrict__ alpha) {
+    append_wrow_alpha((int)blockIdx.x, W, ld, n, lvec, scal, zfw, alpha1, alpha);
 }
 
 // The HBM-streaming sweep: per candidate j
@@ -2554,8 +2611,16 @@ __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__
                                                       const double* __restrict__ lvec, const double* __restrict__ scal,
                                                       double* __restrict__ V, long ldv, int n, double* __restrict__ sres,
                                                       double* __restrict__ mu, double* __restrict__ var, int kernel,
-                                                      double* __restrict__ bmax) {
-    const long j = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+                                                      double* __restrict__ bmax, int extra, double* __restrict__ W, long ldw,
+                                                      const double* __restrict__ zfw, double* __restrict__ alpha1,
+                                                      double* __restrict__ alpha) {
+    // the first `extra` workgroups complete the factor update (new row of W, alpha); the others stream V
+    if ((int)blockIdx.x < extra) {
+        append_wrow_alpha((int)blockIdx.x, W, ldw, n, lvec, scal, zfw, alpha1, alpha);
+        return;
+    }
+    const long blk = (long)blockIdx.x - extra;
+    const long j = (blk * 256 + threadIdx.x) * VEC;
     double mx = -INFINITY;           // the largest updated mean among this thread's candidates
     if (j < m) {
     const int d = (D > 0) ? D : d_rt;
@@ -2633,7 +2698,7 @@ __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) bmax[blockIdx.x] = fmax(fmax(wm[0], wm[1]), fmax(wm[2], wm[3]));
+    if (threadIdx.x == 0) bmax[blk] = fmax(fmax(wm[0], wm[1]), fmax(wm[2], wm[3]));
 }
 
 
