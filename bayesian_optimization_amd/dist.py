@@ -55,6 +55,23 @@ def global_argmax(local_best: float, local_index: int, offset: int, device=None)
     return pick_best(vals[:, 0], vals[:, 1].astype(np.int64))
 
 
+def global_argmax_payload(local_best: float, local_index: int, offset: int, payload, device=None):
+    """global_argmax that also hands every rank a small vector belonging to the winner (the coordinates of the chosen
+    candidate): one all-gather of (value, global index, payload...) per rank instead of a gather followed by a sum."""
+    gi = int(local_index) + int(offset)
+    payload = np.ascontiguousarray(payload, dtype=np.float64).reshape(-1)
+    if not _is_dist():
+        return float(local_best), gi, payload.copy()
+    world = dist.get_world_size()
+    mine = torch.from_numpy(np.concatenate(([float(local_best), float(gi)], payload))).to(_exchange_device(device))
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    rows = np.stack([t.cpu().numpy() for t in allv])                 # indices < 2^53 are exact in f64
+    best, gidx = pick_best(rows[:, 0], rows[:, 1].astype(np.int64))
+    owner = int(np.flatnonzero(rows[:, 1].astype(np.int64) == gidx)[0])
+    return best, gidx, rows[owner, 2:].copy()
+
+
 def global_first_at_least(gp, threshold, offset, fallback):
     """Lowest GLOBAL index whose acquisition value is >= threshold (the tie-tolerant argmax once the global maximum is
     known): each rank scans its block, one all-reduce(MAX) of the negated index picks the minimum."""
@@ -162,8 +179,8 @@ def allreduce_sum(vec, device=None):
 class ShardedLoop:
     """Frozen-theta BO loop (single-factor posterior, GP/BayesOptFcn_v1.m:73-83) with the candidate rows -- and with them the
     resident V = W Ks^T -- split over ranks.  Every rank holds the same small model and applies the same border-append, so
-    the model needs no exchange; per iteration the data path exchanges max(Mu) (one double), the per-rank argmax pairs and
-    the d coordinates of the chosen candidate."""
+    the model needs no exchange; per iteration the data path has two exchanges: all-reduce(MAX) of max(Mu) (one double) and
+    one all-gather of (acquisition max, global index, the d coordinates of that candidate) per rank."""
 
     def __init__(self, gp, candidates_local, offset: int = 0):
         self.gp = gp
@@ -175,9 +192,7 @@ class ShardedLoop:
     def propose(self, acq=0, kappa=0.01):
         """(global index, acquisition value, coordinates) of the next point; identical on every rank."""
         idx, best = self.gp.acquire(acq, kappa, 2, self.mu_max)
-        gbest, gidx = global_argmax(best, idx, self.offset, self.gp.device)
-        mine = self.offset <= gidx < self.offset + len(self.X)
-        x = allreduce_sum(self.X[gidx - self.offset] if mine else np.zeros(self.X.shape[1]), self.gp.device)
+        gbest, gidx, x = global_argmax_payload(best, idx, self.offset, self.X[idx], self.gp.device)
         return gidx, gbest, x
 
     def observe(self, x_new, y_new):

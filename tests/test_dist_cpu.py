@@ -31,6 +31,10 @@ def _worker(rank, world, port, q):
         mu_max = gdist.allreduce_max(float(mu[lo:hi].max()))
         li = int(np.argmax(ei[lo:hi]))
         best, gi = gdist.global_argmax(float(ei[lo:hi][li]), li, lo)
+        # the same exchange carrying the winner's coordinates: every rank must receive those of global index 100
+        coords = np.stack([np.arange(m_total) * 0.5, -np.arange(m_total, dtype=float)], axis=1)
+        best2, gi2, x = gdist.global_argmax_payload(float(ei[lo:hi][li]), li, lo, coords[lo:hi][li])
+        assert (best2, gi2) == (best, gi) and np.array_equal(x, coords[gi])
         q.put((rank, lo, hi, mu_max, best, gi))
     finally:
         dist.destroy_process_group()
