@@ -764,15 +764,14 @@ int append_check(gpbo_ctx* ctx, const double* x_new) {
 
 // factor update (O(n^2)) + the HBM-streaming sweep over the resident V with max(mu) folded into its epilogue.
 // Leaves max(mu) in inc_dev[1].  Call timing_begin first.
-int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new) {
+int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new, bool defer_last_max = false) {
     const int n = (int)ctx->n;
     const long ld = ctx->n_pad;
     PointArg pa;
     for (int t = 0; t < MAX_D; ++t) pa.x[t] = (t < ctx->d) ? x_new[t] / ctx->theta[t] : 0.0;
     Scope tot(ctx, T_TOTAL);
-    hipLaunchKernelGGL(k_step_begin, dim3(1), dim3(64), 0, ctx->stream, pa, ctx->xnew_dev, ctx->info_dev);
     hipLaunchKernelGGL(k_append_kvec, dim3((unsigned)((ctx->n_pad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xts, n,
-                       (int)ctx->n_pad, ctx->d, (const double*)ctx->xnew_dev, ctx->kvec, ctx->kernel);
+                       (int)ctx->n_pad, ctx->d, pa, ctx->xnew_dev, ctx->info_dev, ctx->kvec, ctx->kernel);
     hipLaunchKernelGGL(k_append_lvec, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const double*)ctx->bufW, ld, n,
                        (const double*)ctx->kvec, ctx->lvec);
     hipLaunchKernelGGL(k_append_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->lvec, ctx->zfw, ctx->yv, n,
@@ -796,7 +795,9 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new) {
     const long sweep_blocks = (ctx->m % 2 == 0) ? (ctx->m / 2 + 255) / 256 : (ctx->m + 255) / 256;
     const int b2 = (int)std::min<long>(256, (sweep_blocks + 255) / 256);
     hipLaunchKernelGGL(k_max_stage, dim3(b2), dim3(256), 0, ctx->stream, (const double*)ctx->bmax, sweep_blocks, ctx->red_v, (double*)nullptr);
-    hipLaunchKernelGGL(k_max_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->red_v, (long)b2, ctx->inc_dev + 1, ctx->inc_dev);
+    // (deferred: the acquisition kernel that follows takes the maximum of the b2 second-stage results itself)
+    if (!defer_last_max)
+        hipLaunchKernelGGL(k_max_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->red_v, (long)b2, ctx->inc_dev + 1, ctx->inc_dev);
     HIPCHK(hipGetLastError());
     return GPBO_OK;
 }
@@ -805,8 +806,14 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new) {
 int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumbent, bool store, bool inc_ready = false) {
     if (acq < 0 || acq > 2) BADARG("acquire: unknown acquisition");
     Scope s(ctx, T_ACQ);
+    const double* inc_parts = nullptr;
+    int n_parts = 0;
     if (mode == GPBO_INCUMBENT_MAX_MU && inc_ready) {
-        // the max stage that just ran has written max(mu) into the incumbent slot as well
+        // the append sweep that was just enqueued left the second-stage maxima of mu in red_v: the acquisition kernel reduces
+        // them itself and fills the incumbent and max(mu) slots (the third stage has no launch of its own)
+        const long sweep_blocks = (ctx->m % 2 == 0) ? (ctx->m / 2 + 255) / 256 : (ctx->m + 255) / 256;
+        n_parts = (int)std::min<long>(256, (sweep_blocks + 255) / 256);
+        inc_parts = ctx->red_v;
     } else if (mode == GPBO_INCUMBENT_MAX_MU)
         hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, (const double*)(ctx->inc_dev + 1));
     else if (mode == GPBO_INCUMBENT_MAX_Y)
@@ -818,10 +825,12 @@ int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incum
     const unsigned blocks = (unsigned)((ctx->m + ACQ_SPAN - 1) / ACQ_SPAN);
     if (store)
         hipLaunchKernelGGL(k_acquire_argmax<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, (const double*)ctx->var,
-                           (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi);
+                           (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi, inc_parts, n_parts,
+                           ctx->inc_dev);
     else
         hipLaunchKernelGGL(k_acquire_argmax<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, (const double*)ctx->var,
-                           (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi);
+                           (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi, inc_parts, n_parts,
+                           ctx->inc_dev);
     // (the last argmax stage, over the `blocks` per-workgroup results, runs inside the end-of-step launch: step_fetch)
     HIPCHK(hipGetLastError());
     ctx->have_acq = store;       // (not stored: the array still holds the values of an earlier posterior)
@@ -914,7 +923,7 @@ int append_acquire_impl(gpbo_ctx* ctx, const double* x_new, double y_new, int ac
     if (acq < 0 || acq > 2) BADARG("append_acquire: unknown acquisition");
     if (mode < 0 || mode > 2) BADARG("append_acquire: unknown incumbent mode");
     timing_begin(ctx);
-    CHK(append_enqueue(ctx, x_new, y_new));
+    CHK(append_enqueue(ctx, x_new, y_new, mode == GPBO_INCUMBENT_MAX_MU));
     CHK(acquire_enqueue(ctx, acq, kappa, mode, incumbent, false, true));
     StepResult r{};
     CHK(step_fetch(ctx, &r, true, true));

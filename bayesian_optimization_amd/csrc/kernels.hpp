@@ -1549,16 +1549,10 @@ __global__ __launch_bounds__(256) void k_max_stage(const double* __restrict__ a,
     }
 }
 
-// Start of a loop step: the new scaled point goes to device memory and the status word is cleared, in one launch
-// (instead of a host-to-device copy and a fill, each a separate trip through the runtime).
+// The new scaled point of a loop step, passed to the step's first kernel by value.
 struct PointArg {
     double x[MAX_D];
 };
-__global__ void k_step_begin(PointArg p, double* __restrict__ xnew, int* __restrict__ info) {
-    const int t = threadIdx.x;
-    if (t < MAX_D) xnew[t] = p.x[t];
-    if (t == 0) *info = 0;
-}
 
 // End of a loop step: everything the host reads back, gathered into one block (pinned host memory mapped into the
 // device's address space: the kernel's stores are the transfer).  res: [0..7] params head, [8] info, [9] max(mu),
@@ -1715,15 +1709,34 @@ __global__ __launch_bounds__(256) void k_acquire(const double* __restrict__ mu, 
 // lowest index; the workgroup's (value, index) goes to part_v / part_i.  STORE: also write the values to out.
 constexpr int ACQ_PER = 8;
 constexpr int ACQ_SPAN = 256 * ACQ_PER;
+// n_parts > 0: the incumbent is the maximum of inc_parts[0 .. n_parts) (n_parts <= 256: the second-stage results of the
+// max(mu) reduction), which every workgroup reduces for itself instead of waiting for a launch that does it once; workgroup 0
+// leaves it in inc_out[0] (incumbent) and inc_out[1] (max(mu)).  A maximum does not depend on the order it is taken in.
 template <bool STORE>
 __global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict__ mu, const double* __restrict__ var, long m, int acq,
                                                         double kappa, const double* __restrict__ inc_ptr, double* __restrict__ out,
-                                                        double* __restrict__ part_v, long* __restrict__ part_i) {
+                                                        double* __restrict__ part_v, long* __restrict__ part_i,
+                                                        const double* __restrict__ inc_parts = nullptr, int n_parts = 0,
+                                                        double* __restrict__ inc_out = nullptr) {
     __shared__ double rv[256];
     __shared__ long ri[256];
     const int tid = threadIdx.x;
     const long base = (long)blockIdx.x * ACQ_SPAN;
-    const double inc = *inc_ptr;
+    double inc;
+    if (n_parts > 0) {
+        double v = (tid < n_parts) ? inc_parts[tid] : -INFINITY;
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        if ((tid & 63) == 0) rv[tid >> 6] = v;
+        __syncthreads();
+        inc = fmax(fmax(rv[0], rv[1]), fmax(rv[2], rv[3]));
+        __syncthreads();                                   // rv is reused below
+        if (blockIdx.x == 0 && tid == 0) {
+            inc_out[0] = inc;
+            inc_out[1] = inc;
+        }
+    } else {
+        inc = *inc_ptr;
+    }
     double bv = -INFINITY;
     long bi = INT64_MAX;
 #pragma unroll
@@ -2480,22 +2493,27 @@ __global__ __launch_bounds__(256) void k_lml_store(const double* __restrict__ pa
 enum { A_DNEW = 0, A_ZNEW = 1, A_LL = 2, A_LZ = 3 };
 
 // kvec[i] = k(x_i, x_new) for i < n (0 for the pad); also records the new scaled point as column n of Xts.
-__global__ __launch_bounds__(256) void k_append_kvec(double* __restrict__ Xts, int n, int n_pad, int d,
-                                                     const double* __restrict__ xnew, double* __restrict__ kvec, int kernel) {
+// First launch of a loop step: the new scaled point arrives as a kernel argument and is left in device memory (xnew_out)
+// for the kernels that follow, and the status word is cleared -- no launch, copy or fill of their own for either.
+__global__ __launch_bounds__(256) void k_append_kvec(double* __restrict__ Xts, int n, int n_pad, int d, PointArg p,
+                                                     double* __restrict__ xnew_out, int* __restrict__ info,
+                                                     double* __restrict__ kvec, int kernel) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < MAX_D) xnew_out[i] = p.x[i];
+    if (i == 0) *info = 0;
     if (i >= n_pad) return;
     double v = 0.0;
     if (i < n) {
         double Dq = 0.0;
         for (int t = 0; t < d; ++t) {
-            const double df = Xts[(long)t * n_pad + i] - xnew[t];
+            const double df = Xts[(long)t * n_pad + i] - p.x[t];
             Dq += df * df;
         }
         v = kern_eval(Dq, kernel);
     }
     kvec[i] = v;
     if (i == n)
-        for (int t = 0; t < d; ++t) Xts[(long)t * n_pad + n] = xnew[t];
+        for (int t = 0; t < d; ++t) Xts[(long)t * n_pad + n] = p.x[t];
 }
 
 // l = W[0:n,0:n] * kvec  (one wave per row, lanes along the row)
