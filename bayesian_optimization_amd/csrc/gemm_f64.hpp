@@ -273,6 +273,82 @@ __device__ __forceinline__ void gemm_tile_64x128(const double* __restrict__ A, l
 }
 
 // ---------------------------------------------------------------------------------------
+// Quarter form: one 256-thread workgroup computes a 64 x 64 tile (waves 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles), both
+// operands row-major with k contiguous.  For products with so few 128 x 128 tiles that even the half tiles leave CUs idle
+// or give some of them two: a 64 x 64 x 128 tile is 3.4 us of MFMA time, and four workgroups fit a CU (LDS 36,864 B each).
+// Per flop it moves twice the operand bytes of the square tile.  Same sums in the same order as the other forms.
+constexpr int QUARTER_M = 64;
+constexpr int QUARTER_OP_DOUBLES = QUARTER_M * LDS_RK;        // 1152 per operand
+constexpr int QUARTER_BUF_DOUBLES = 2 * QUARTER_OP_DOUBLES;
+constexpr int QUARTER_LDS_DOUBLES = 2 * QUARTER_BUF_DOUBLES;  // 4608 doubles
+
+struct StageQuarter {
+    f64x2 a[2];
+    f64x2 b[2];
+};
+
+__device__ __forceinline__ void load_quarter(StageQuarter& s, const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                             long ldb, int k0, int tid) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int q = tid + 256 * p;                          // 8 lanes = one row's 16 k = 128 contiguous bytes
+        s.a[p] = *reinterpret_cast<const f64x2*>(A + (long)(q >> 3) * lda + k0 + 2 * (q & 7));
+        s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(q >> 3) * ldb + k0 + 2 * (q & 7));
+    }
+}
+
+__device__ __forceinline__ void store_quarter(const StageQuarter& s, double* lds, int tid) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int q = tid + 256 * p;
+        *reinterpret_cast<f64x2*>(lds + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.a[p];
+        *reinterpret_cast<f64x2*>(lds + QUARTER_OP_DOUBLES + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.b[p];
+    }
+}
+
+// acc[ta][tb][r] of this lane is element (row, col) of the 64 x 64 tile with
+//   row = (w >> 1) * 32 + ta * 16 + (lane >> 4) + 4 r,  col = (w & 1) * 32 + tb * 16 + (lane & 15).
+__device__ __forceinline__ void gemm_tile_64x64(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                                int k_begin, int k_end, f64x4 (&acc)[2][2], double* lds) {
+    if (k_begin >= k_end) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    StageQuarter st;
+    load_quarter(st, A, lda, B, ldb, k_begin, tid);
+    store_quarter(st, lds, tid);
+    __syncthreads();
+    int buf = 0;
+    const int a_off = (wr * 32 + (lane & 15)) * LDS_RK + (lane >> 4);
+    const int b_off = QUARTER_OP_DOUBLES + (wc * 32 + (lane & 15)) * LDS_RK + (lane >> 4);
+    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
+        load_quarter(st, A, lda, B, ldb, kn, tid);
+        const double* a_l = lds + buf * QUARTER_BUF_DOUBLES + a_off;
+        const double* b_l = lds + buf * QUARTER_BUF_DOUBLES + b_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = a_l[kk * 4 + t * 16 * LDS_RK];
+                bf[t] = b_l[kk * 4 + t * 16 * LDS_RK];
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (kk == 2) store_quarter(st, lds + (buf ^ 1) * QUARTER_BUF_DOUBLES, tid);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Wide form: one 512-thread workgroup (eight waves, 2 x 4, each still 64x64) computes a 128 x 256 tile
 //   acc(i,j) = sum_k A(i,k) B(k,j),  A row-major with k contiguous (a row panel of W), B k-major with j contiguous.
 // Per k-step a thread issues six 16-byte global loads instead of eight (the A tile is shared by twice as many MFMAs),

@@ -342,6 +342,12 @@ long syrk_half_max() {
     return v;
 }
 
+// ... and with at most this many on quarter tiles (k_syrk_update_quarter).  0 = never.
+long syrk_quarter_max() {
+    static const long v = getenv("GPBO_SYRK_QUARTER_MAX") ? atol(getenv("GPBO_SYRK_QUARTER_MAX")) : 4096;
+    return v;
+}
+
 // F(group): the latency-bound part.  Needs the group's block columns up to date.
 // Inside the group the panels are applied to the group's own block columns recursively: factor the left half, update
 // the right half's columns with the whole left half at once (K = 128 * half), factor the right half.  The number of
@@ -475,7 +481,10 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
             chol_factor_group(ctx->stream, ctx, A, info_dev, p0, g);
             const int T = nb - (p0 + g);
             const long tiles = (long)T * (T + 1) / 2;
-            if (T > 0 && tiles * ctx->batch <= syrk_half_max())
+            if (T > 0 && tiles * ctx->batch <= syrk_quarter_max())
+                hipLaunchKernelGGL(k_syrk_update_quarter, dim3((unsigned)(4 * tiles), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
+                                   ctx->stream, A, ld, p0 + g, p0 * PB, g * PB, ctx->bs);
+            else if (T > 0 && tiles * ctx->batch <= syrk_half_max())
                 hipLaunchKernelGGL(k_syrk_update_half<true>, dim3((unsigned)(2 * tiles), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
                                    ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
             else if (T > 0) {

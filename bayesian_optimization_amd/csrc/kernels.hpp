@@ -870,6 +870,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update_half(double* __
             for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
 }
 
+// The same update on 64 x 64 quarter tiles (gemm_tile_64x64), for launches with so few tiles that the half tiles still leave
+// CUs idle or double up on some: four workgroups per 128 x 128 tile, blockIdx.x = 4 * tile + 2 * (row half) + (column half),
+// over the lower tiles of the square of blocks starting at b0.
+__global__ __launch_bounds__(GEMM_THREADS, 4) void k_syrk_update_quarter(double* __restrict__ A, long ld, int b0, int kcol0, int klen,
+                                                                         BatchStride bs) {
+    A += blockIdx.z * bs.mat;
+    const int hr = (blockIdx.x >> 1) & 1, hc = blockIdx.x & 1;
+    int i, j;
+    tri_decode(blockIdx.x >> 2, i, j);
+    const int ib = b0 + i, jb = b0 + j;
+    __shared__ double lds[QUARTER_LDS_DOUBLES];
+    const double* Pi = A + ((long)ib * PB + hr * QUARTER_M) * ld + kcol0;
+    const double* Pj = A + ((long)jb * PB + hc * QUARTER_M) * ld + kcol0;
+    double* C = A + ((long)ib * PB + hr * QUARTER_M) * ld + (long)jb * PB + hc * QUARTER_M;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 32 + (lane & 15);
+    f64x4 acc[2][2];            // start at -C, store -(acc): see k_syrk_update
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16];
+    gemm_tile_64x64(Pi, ld, Pj, ld, 0, klen, acc, lds);
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
+}
+
 // Zero the strict upper triangle (the factorisation leaves stale values there).
 __global__ __launch_bounds__(256) void k_zero_upper(double* __restrict__ A, int n_pad, BatchStride bs) {
     A += blockIdx.z * bs.mat;
