@@ -361,7 +361,11 @@ void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, 
     if (g > 1) {
         const int h = g / 2, c0 = p0 + h;          // columns c0 .. p0 + g - 1 take panels p0 .. c0 - 1
         chol_factor_group(st, ctx, A, info_dev, p0, h);
-        if ((long)(g - h) * (nb - c0) * S <= syrk_half_max())
+        static const long rect_quarter_max = getenv("GPBO_SYRK_RECT_QUARTER_MAX") ? atol(getenv("GPBO_SYRK_RECT_QUARTER_MAX")) : 4096;
+        if ((long)(g - h) * (nb - c0) * S <= rect_quarter_max)
+            hipLaunchKernelGGL(k_syrk_update_quarter<false>, dim3(4 * (g - h), nb - c0, S), dim3(GEMM_THREADS), 0, st, A, ld, c0, c0,
+                               p0 * PB, h * PB, ctx->bs);
+        else if ((long)(g - h) * (nb - c0) * S <= syrk_half_max())
             hipLaunchKernelGGL(k_syrk_update_half<false>, dim3(2 * (g - h), nb - c0, S), dim3(GEMM_THREADS), 0, st, A, ld, c0, c0,
                                p0 * PB, h * PB, ctx->bs);
         else
@@ -482,8 +486,8 @@ int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
             const int T = nb - (p0 + g);
             const long tiles = (long)T * (T + 1) / 2;
             if (T > 0 && tiles * ctx->batch <= syrk_quarter_max())
-                hipLaunchKernelGGL(k_syrk_update_quarter, dim3((unsigned)(4 * tiles), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
-                                   ctx->stream, A, ld, p0 + g, p0 * PB, g * PB, ctx->bs);
+                hipLaunchKernelGGL(k_syrk_update_quarter<true>, dim3((unsigned)(4 * tiles), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
+                                   ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);
             else if (T > 0 && tiles * ctx->batch <= syrk_half_max())
                 hipLaunchKernelGGL(k_syrk_update_half<true>, dim3((unsigned)(2 * tiles), 1, (unsigned)ctx->batch), dim3(GEMM_THREADS), 0,
                                    ctx->stream, A, ld, p0 + g, p0 + g, p0 * PB, g * PB, ctx->bs);

@@ -873,13 +873,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update_half(double* __
 // The same update on 64 x 64 quarter tiles (gemm_tile_64x64), for launches with so few tiles that the half tiles still leave
 // CUs idle or double up on some: four workgroups per 128 x 128 tile, blockIdx.x = 4 * tile + 2 * (row half) + (column half),
 // over the lower tiles of the square of blocks starting at b0.
-__global__ __launch_bounds__(GEMM_THREADS, 4) void k_syrk_update_quarter(double* __restrict__ A, long ld, int b0, int kcol0, int klen,
-                                                                         BatchStride bs) {
+// !TRI: a rectangle of blocks, ib = b0 + blockIdx.y, jb = jb0 + (blockIdx.x >> 2) (the updates inside a group of panels).
+template <bool TRI>
+__global__ __launch_bounds__(GEMM_THREADS, 4) void k_syrk_update_quarter(double* __restrict__ A, long ld, int b0, int jb0, int kcol0,
+                                                                         int klen, BatchStride bs) {
     A += blockIdx.z * bs.mat;
     const int hr = (blockIdx.x >> 1) & 1, hc = blockIdx.x & 1;
-    int i, j;
-    tri_decode(blockIdx.x >> 2, i, j);
-    const int ib = b0 + i, jb = b0 + j;
+    int ib, jb;
+    if (TRI) {
+        int i, j;
+        tri_decode(blockIdx.x >> 2, i, j);
+        ib = b0 + i;
+        jb = b0 + j;
+    } else {
+        ib = b0 + blockIdx.y;
+        jb = jb0 + (blockIdx.x >> 2);
+        __builtin_amdgcn_s_setprio(2);
+    }
     __shared__ double lds[QUARTER_LDS_DOUBLES];
     const double* Pi = A + ((long)ib * PB + hr * QUARTER_M) * ld + kcol0;
     const double* Pj = A + ((long)jb * PB + hc * QUARTER_M) * ld + kcol0;
