@@ -273,41 +273,49 @@ __device__ __forceinline__ void gemm_tile_64x128(const double* __restrict__ A, l
 }
 
 // ---------------------------------------------------------------------------------------
-// Quarter form: one 256-thread workgroup computes a 64 x 64 tile (waves 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles), both
-// operands row-major with k contiguous.  For products with so few 128 x 128 tiles that even the half tiles leave CUs idle
-// or give some of them two: a 64 x 64 x 128 tile is 3.4 us of MFMA time, and four workgroups fit a CU (LDS 36,864 B each).
+// Quarter form: one 256-thread workgroup computes a 64 x 64 tile (waves 2 x 2, each 32 x 32 = 2 x 2 MFMA tiles); A row-major
+// with k contiguous, B either way.  For products with so few 128 x 128 tiles that even the half tiles leave CUs idle
+// or give some of them two: a 64 x 64 x 128 tile is 3.4 us of MFMA time, and four workgroups fit a CU (LDS 38,912 B each).
 // Per flop it moves twice the operand bytes of the square tile.  Same sums in the same order as the other forms.
 constexpr int QUARTER_M = 64;
-constexpr int QUARTER_OP_DOUBLES = QUARTER_M * LDS_RK;        // 1152 per operand
-constexpr int QUARTER_BUF_DOUBLES = 2 * QUARTER_OP_DOUBLES;
-constexpr int QUARTER_LDS_DOUBLES = 2 * QUARTER_BUF_DOUBLES;  // 4608 doubles
+constexpr int QUARTER_A_DOUBLES = QUARTER_M * LDS_RK;         // 1152: row-major image [64 x][18]
+constexpr int QUARTER_LD = 80;                                // k-major image of a 64-wide B tile: 640 B == 128 mod 256
+constexpr int QUARTER_B_DOUBLES = TK * QUARTER_LD;            // 1280 (the row-major image needs 1152)
+constexpr int QUARTER_BUF_DOUBLES = QUARTER_A_DOUBLES + QUARTER_B_DOUBLES;
+constexpr int QUARTER_LDS_DOUBLES = 2 * QUARTER_BUF_DOUBLES;  // 4864 doubles = 38,912 B
 
 struct StageQuarter {
     f64x2 a[2];
     f64x2 b[2];
 };
 
+// B_KCONTIG as in load_tile: true = B row-major with k contiguous, false = k-major (element (j, k) at B[k * ldb + j]).
+template <bool B_KCONTIG>
 __device__ __forceinline__ void load_quarter(StageQuarter& s, const double* __restrict__ A, long lda, const double* __restrict__ B,
                                              long ldb, int k0, int tid) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int q = tid + 256 * p;                          // 8 lanes = one row's 16 k = 128 contiguous bytes
         s.a[p] = *reinterpret_cast<const f64x2*>(A + (long)(q >> 3) * lda + k0 + 2 * (q & 7));
-        s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(q >> 3) * ldb + k0 + 2 * (q & 7));
+        if (B_KCONTIG) s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(q >> 3) * ldb + k0 + 2 * (q & 7));
+        else s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(k0 + (q >> 5)) * ldb + 2 * (q & 31));   // 32 lanes = one 512 B k-row
     }
 }
 
+template <bool B_KCONTIG>
 __device__ __forceinline__ void store_quarter(const StageQuarter& s, double* lds, int tid) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int q = tid + 256 * p;
         *reinterpret_cast<f64x2*>(lds + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.a[p];
-        *reinterpret_cast<f64x2*>(lds + QUARTER_OP_DOUBLES + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.b[p];
+        if (B_KCONTIG) *reinterpret_cast<f64x2*>(lds + QUARTER_A_DOUBLES + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.b[p];
+        else *reinterpret_cast<f64x2*>(lds + QUARTER_A_DOUBLES + (q >> 5) * QUARTER_LD + 2 * (q & 31)) = s.b[p];
     }
 }
 
 // acc[ta][tb][r] of this lane is element (row, col) of the 64 x 64 tile with
 //   row = (w >> 1) * 32 + ta * 16 + (lane >> 4) + 4 r,  col = (w & 1) * 32 + tb * 16 + (lane & 15).
+template <bool B_KCONTIG = true>
 __device__ __forceinline__ void gemm_tile_64x64(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                                 int k_begin, int k_end, f64x4 (&acc)[2][2], double* lds) {
     if (k_begin >= k_end) return;
@@ -315,15 +323,17 @@ __device__ __forceinline__ void gemm_tile_64x64(const double* __restrict__ A, lo
     const int lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     StageQuarter st;
-    load_quarter(st, A, lda, B, ldb, k_begin, tid);
-    store_quarter(st, lds, tid);
+    load_quarter<B_KCONTIG>(st, A, lda, B, ldb, k_begin, tid);
+    store_quarter<B_KCONTIG>(st, lds, tid);
     __syncthreads();
     int buf = 0;
     const int a_off = (wr * 32 + (lane & 15)) * LDS_RK + (lane >> 4);
-    const int b_off = QUARTER_OP_DOUBLES + (wc * 32 + (lane & 15)) * LDS_RK + (lane >> 4);
+    const int b_off = QUARTER_A_DOUBLES + (B_KCONTIG ? (wc * 32 + (lane & 15)) * LDS_RK + (lane >> 4)
+                                                     : wc * 32 + (lane & 15) + (lane >> 4) * QUARTER_LD);
+    constexpr int b_kstride = B_KCONTIG ? 4 : 4 * QUARTER_LD, b_tstride = B_KCONTIG ? 16 * LDS_RK : 16;
     for (int k0 = k_begin; k0 < k_end; k0 += TK) {
         const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
-        load_quarter(st, A, lda, B, ldb, kn, tid);
+        load_quarter<B_KCONTIG>(st, A, lda, B, ldb, kn, tid);
         const double* a_l = lds + buf * QUARTER_BUF_DOUBLES + a_off;
         const double* b_l = lds + buf * QUARTER_BUF_DOUBLES + b_off;
 #pragma unroll
@@ -332,7 +342,7 @@ __device__ __forceinline__ void gemm_tile_64x64(const double* __restrict__ A, lo
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 af[t] = a_l[kk * 4 + t * 16 * LDS_RK];
-                bf[t] = b_l[kk * 4 + t * 16 * LDS_RK];
+                bf[t] = b_l[kk * b_kstride + t * b_tstride];
             }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -341,7 +351,7 @@ __device__ __forceinline__ void gemm_tile_64x64(const double* __restrict__ A, lo
                 for (int tb = 0; tb < 2; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ta], bf[tb], acc[ta][tb], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-            if (kk == 2) store_quarter(st, lds + (buf ^ 1) * QUARTER_BUF_DOUBLES, tid);
+            if (kk == 2) store_quarter<B_KCONTIG>(st, lds + (buf ^ 1) * QUARTER_BUF_DOUBLES, tid);
         }
         __syncthreads();
         buf ^= 1;

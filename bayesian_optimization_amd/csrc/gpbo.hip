@@ -587,6 +587,13 @@ int launch_inverse(gpbo_ctx* ctx, const double* L, double* W, double* T) {
     for (int sb = 1; sb < nb; sb *= 2) {
         const int pairs = (nb + 2 * sb - 1) / (2 * sb);
         dim3 grid(sb, sb, pairs * S);  // step1: (ib, jb), step2: (jb, reversed ib): the slow index orders tiles longest first
+        static const long inv_quarter_max = getenv("GPBO_INV_QUARTER_MAX") ? atol(getenv("GPBO_INV_QUARTER_MAX")) : 1024;
+        if ((long)sb * sb * pairs * S <= inv_quarter_max) {
+            dim3 gq(4 * sb, sb, pairs * S);
+            hipLaunchKernelGGL(k_inv_step1_quarter, gq, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb, ctx->bs);
+            hipLaunchKernelGGL(k_inv_step2_quarter, gq, dim3(GEMM_THREADS), 0, ctx->stream, W, (const double*)T, ld, sb, nb, ctx->bs);
+            continue;
+        }
         if ((long)sb * sb * pairs * S <= inv_half_max) {      // too few tiles for the chip: half tiles
             dim3 gh(2 * sb, sb, pairs * S);
             hipLaunchKernelGGL(k_inv_step1<true>, gh, dim3(GEMM_THREADS), 0, ctx->stream, L, (const double*)W, T, ld, sb, nb, ctx->bs);

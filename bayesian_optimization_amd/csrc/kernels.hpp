@@ -1036,6 +1036,73 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restric
             for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = -acc[ta][tb][r];
 }
 
+// Both steps on 64 x 64 quarter tiles (gemm_tile_64x64, k-major second operand): blockIdx.x = 4 * (x index) + 2 * (row half)
+// + (column half).  A level of the doubling is as long as its longest tile (the products shrink with the distance from the
+// diagonal), and four small workgroups per CU even that out better than two halves; same sums in the same order.
+__global__ __launch_bounds__(GEMM_THREADS, 4) void k_inv_step1_quarter(const double* __restrict__ L, const double* __restrict__ W,
+                                                                       double* __restrict__ T, long ld, int sb, int nb, BatchStride bs) {
+    const int pairs = (nb + 2 * sb - 1) / (2 * sb);
+    const int q = blockIdx.z % pairs, slot = blockIdx.z / pairs;
+    L += slot * bs.mat;
+    W += slot * bs.mat;
+    T += slot * bs.mat;
+    const int a0 = 2 * q * sb, b0 = a0 + sb;
+    const int rows = min(sb, nb - b0);
+    const int ib = blockIdx.x >> 2, jb = blockIdx.y;
+    if (ib >= rows) return;
+    const int hr = (blockIdx.x >> 1) & 1, hc = blockIdx.x & 1;
+    __shared__ double ldq[QUARTER_LDS_DOUBLES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 32 + (lane & 15);
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const double* Ap = L + ((long)(b0 + ib) * PB + hr * QUARTER_M) * ld + (long)a0 * PB;
+    const double* Bp = W + (long)a0 * PB * ld + (long)(a0 + jb) * PB + hc * QUARTER_M;
+    gemm_tile_64x64<false>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, ldq);
+    double* C = T + ((long)(b0 + ib) * PB + hr * QUARTER_M) * ld + (long)(a0 + jb) * PB + hc * QUARTER_M;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = acc[ta][tb][r];
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 4) void k_inv_step2_quarter(double* __restrict__ W, const double* __restrict__ T, long ld,
+                                                                       int sb, int nb, BatchStride bs) {
+    const int pairs = (nb + 2 * sb - 1) / (2 * sb);
+    const int q = blockIdx.z % pairs, slot = blockIdx.z / pairs;
+    W += slot * bs.mat;
+    T += slot * bs.mat;
+    const int a0 = 2 * q * sb, b0 = a0 + sb;
+    const int rows = min(sb, nb - b0);
+    const int ib = rows - 1 - (int)blockIdx.y, jb = blockIdx.x >> 2;      // long tiles (large ib) first
+    if (ib < 0) return;
+    const int hr = (blockIdx.x >> 1) & 1, hc = blockIdx.x & 1;
+    __shared__ double ldq[QUARTER_LDS_DOUBLES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 32 + (lane & 15);
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const double* Ap = W + ((long)(b0 + ib) * PB + hr * QUARTER_M) * ld + (long)b0 * PB;
+    const double* Bp = T + (long)b0 * PB * ld + (long)(a0 + jb) * PB + hc * QUARTER_M;
+    // W[B,B] is lower triangular: the upper half of the rows ends 64 columns earlier (those products are exact zeros)
+    gemm_tile_64x64<false>(Ap, ld, Bp, ld, 0, ib * PB + (hr + 1) * QUARTER_M, acc, ldq);
+    double* C = W + ((long)(b0 + ib) * PB + hr * QUARTER_M) * ld + (long)(a0 + jb) * PB + hc * QUARTER_M;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
+}
+
 // Sums of N (a power of two, <= 32) per-lane values over the 64 lanes of a wave: on return every lane holds the total of
 // value lane / (64 / N).  Each exchange halves the number of values a lane carries (the half it gives up travels to the
 // partner lane): N - 1 exchanges plus a butterfly on the one value left, instead of N butterflies of six exchanges, and
