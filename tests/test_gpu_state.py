@@ -159,7 +159,7 @@ def test_fused_loop_step_equals_append_then_acquire():
 
 def test_factorisation_kernel_choices_agree():
     """The factorisation picks its kernels by size (register-resident or tile-engine panel solve, block inverses inside the
-    diagonal kernel or after the factorisation, whole or half tiles for the trailing update and the inverse).  Forced to
+    diagonal kernel or after the factorisation, whole, half or quarter tiles for the trailing update and the inverse).  Forced to
     the forms that large problems use, a mid-size fit must give the same model: theta1, -logL, factor and posterior."""
     import json
     import subprocess
@@ -180,8 +180,12 @@ nll, g, st = gp.lml_batch(X, y, np.array([[0.4, 0.5, 0.6], [0.3, 0.3, 0.3]]), [0
 np.savez(sys.argv[1], mu=mu, var=var, L=L, a=a, th1=gp.theta1, nll=gp.nll, idx=idx, lml=nll, g=g)
 '''
     outs = []
-    forms = [{}, {'GPBO_TRSM_ROWS_MAX': '0', 'GPBO_SYRK_HALF_MAX': '0', 'GPBO_INV_HALF_MAX': '0'},
-             {'GPBO_CHOL_GROUP': '4', 'GPBO_SYRK_HALF_MAX': '100000', 'GPBO_INV_HALF_MAX': '100000'}]
+    noq = {'GPBO_SYRK_QUARTER_MAX': '0', 'GPBO_SYRK_RECT_QUARTER_MAX': '0', 'GPBO_INV_QUARTER_MAX': '0'}
+    forms = [{},                                                                                   # the defaults (quarter tiles at this size)
+             dict(noq, GPBO_TRSM_ROWS_MAX='0', GPBO_SYRK_HALF_MAX='0', GPBO_INV_HALF_MAX='0'),     # 128 x 128 tiles everywhere
+             dict(noq, GPBO_CHOL_GROUP='4', GPBO_SYRK_HALF_MAX='100000', GPBO_INV_HALF_MAX='100000'),   # half tiles, groups of panels
+             {'GPBO_CHOL_GROUP': '4', 'GPBO_SYRK_QUARTER_MAX': '100000', 'GPBO_SYRK_RECT_QUARTER_MAX': '100000',
+              'GPBO_INV_QUARTER_MAX': '100000'}]                                                   # quarter tiles, groups of panels
     for k, env_add in enumerate(forms):
         path = os.path.join(ROOT, 'gpurun_out', 'forms_%d.npz' % k)
         os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -225,7 +229,7 @@ np.savez(sys.argv[1], L=np.frombuffer(hashlib.sha256(np.ascontiguousarray(L).tob
     outs = []
     for k, band in enumerate(('0', '8', '4')):
         path = str(tmp_path / ('band_%d.npz' % k))
-        env = dict(os.environ, GPBO_SYRK_BAND=band, GPBO_SYRK_HALF_MAX='0', GPBO_CHOL_GROUP='1')
+        env = dict(os.environ, GPBO_SYRK_BAND=band, GPBO_SYRK_HALF_MAX='0', GPBO_SYRK_QUARTER_MAX='0', GPBO_CHOL_GROUP='1')
         proc = subprocess.run([sys.executable, '-c', code, path], env=env, cwd=ROOT, capture_output=True, text=True, timeout=150)
         assert proc.returncode == 0, proc.stderr[-2000:]
         outs.append(np.load(path))
