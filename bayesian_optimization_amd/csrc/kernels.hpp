@@ -617,12 +617,26 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     double* Wi8 = Tbuf + TRINV_T_DOUBLES;          // only the MFMA form has (and uses) this space
     GPBO_STAMP(8, 0);
     if (tid == 0) fail_s = -1;
-    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {      // lower triangle -> packed LDS
-        const int r = idx >> 6, c = (idx & 63) * 2;
-        if (c <= r) {
-            const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)r * ld + c);
-            S[tri_off(r) + c] = v.x;
-            if (c + 1 <= r) S[tri_off(r) + c + 1] = v.y;
+    // lower triangle -> packed LDS.  Eight requests per thread go out before the first is waited for (with 1024 threads
+    // that is the whole block in one memory round trip; a load inside the "c <= r" branch is waited for where it is
+    // issued, eight round trips in a row on the factorisation's critical path).  The pairs right of the diagonal are
+    // read as well (they lie inside the block) and dropped.
+    for (int base = 0; base < PB * PB / 2; base += 8 * (int)blockDim.x) {
+        f64x2 v[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = base + it * (int)blockDim.x + tid;
+            const int ii = idx < PB * PB / 2 ? idx : PB * PB / 2 - 1;
+            v[it] = *reinterpret_cast<const f64x2*>(blk + (long)(ii >> 6) * ld + (ii & 63) * 2);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = base + it * (int)blockDim.x + tid;
+            const int r = idx >> 6, c = (idx & 63) * 2;
+            if (idx < PB * PB / 2 && c <= r) {
+                S[tri_off(r) + c] = v[it].x;
+                if (c + 1 <= r) S[tri_off(r) + c + 1] = v[it].y;
+            }
         }
     }
     __syncthreads();
