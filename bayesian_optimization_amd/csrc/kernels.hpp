@@ -945,7 +945,17 @@ __global__ __launch_bounds__(256) void k_inv_copy_diag(double* __restrict__ W, l
     const int p = blockIdx.x;
     double* blk = W + (long)p * PB * ld + (long)p * PB;
     const double* src = Dinv + (long)p * PB * PB;
-    for (int idx = threadIdx.x; idx < PB * PB; idx += 256) blk[(long)(idx >> 7) * ld + (idx & 127)] = src[idx];
+    // pairs of doubles, eight requests per thread in flight (one after the other the copy is a chain of 64 round trips)
+    for (int base = 0; base < PB * PB / 2; base += 8 * 256) {
+        f64x2 v[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const f64x2*>(src + 2 * (base + it * 256 + (int)threadIdx.x));
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = base + it * 256 + (int)threadIdx.x;
+            *reinterpret_cast<f64x2*>(blk + (long)(idx >> 6) * ld + (idx & 63) * 2) = v[it];
+        }
+    }
 }
 
 // step 1: T[B,A] = L[B,A] * W[A,A]      (W[A,A] lower triangular: k >= j)
