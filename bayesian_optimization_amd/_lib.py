@@ -59,7 +59,7 @@ SIGNATURES = {
     'gpbo_acquire': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, _i64p, _dp]),
     'gpbo_first_at_least': (C.c_int, [C.c_void_p, C.c_double, _i64p]),
     'gpbo_acquire_static': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32,
-                                      C.c_double, C.c_void_p, _i64p, _dp, _dp]),
+                                      C.c_double, C.c_void_p, C.c_void_p, _i64p, _dp, _dp]),
     'gpbo_read': (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int64, C.c_int64]),
     'gpbo_predict_ei': (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_double, C.c_int32, C.c_double, _dp, _dp, _dp, _i64p, _dp, _dp]),
     'gpbo_append': (C.c_int, [C.c_void_p, _dp, C.c_double, _dp]),
@@ -72,6 +72,7 @@ SIGNATURES = {
     'gpbo_lml_batch': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, _dp, _dp, _i32p]),
     'gpbo_get_factor': (C.c_int, [C.c_void_p, _dp, _dp]),
     'gpbo_model_scalars': (C.c_int, [C.c_void_p, _dp, _dp, _dp, _i64p]),
+    'gpbo_shape': (C.c_int, [C.c_void_p, _i64p, _i32p, _i64p, _i64p]),
     'gpbo_cond_estimate': (C.c_int, [C.c_void_p, _dp]),
     'gpbo_last_timings': (C.c_int, [C.c_void_p, C.POINTER(Timings)]),
     'gpbo_set_timing': (C.c_int, [C.c_void_p, C.c_int32]),

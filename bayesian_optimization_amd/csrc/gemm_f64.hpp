@@ -358,130 +358,6 @@ __device__ __forceinline__ void gemm_tile_64x64(const double* __restrict__ A, lo
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Wide form: one 512-thread workgroup (eight waves, 2 x 4, each still 64x64) computes a 128 x 256 tile
-//   acc(i,j) = sum_k A(i,k) B(k,j),  A row-major with k contiguous (a row panel of W), B k-major with j contiguous.
-// Per k-step a thread issues six 16-byte global loads instead of eight (the A tile is shared by twice as many MFMAs),
-// and the A panel is fetched once per 256 columns.  LDS: 2 x (128 x 18 + 16 x 272) doubles = 106,496 B, one workgroup
-// per CU, two waves per SIMD as in the 128 x 128 form.
-constexpr int WIDE_N = 256;
-constexpr int WIDE_THREADS = 512;
-constexpr int LDS_LD_W = 272;                               // k-major image of the 256-wide B tile: 2176 B == 128 mod 256
-constexpr int WIDE_A_DOUBLES = 128 * LDS_RK;                // 2304
-constexpr int WIDE_B_DOUBLES = TK * LDS_LD_W;               // 4352
-constexpr int WIDE_BUF_DOUBLES = WIDE_A_DOUBLES + WIDE_B_DOUBLES;
-constexpr int WIDE_LDS_DOUBLES = 2 * WIDE_BUF_DOUBLES;      // 13,312 doubles
-
-struct StageWide {
-    f64x2 a[2];
-    f64x2 b[4];
-};
-
-__device__ __forceinline__ void load_wide(StageWide& s, const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
-                                          int k0, int tid) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int q = tid + WIDE_THREADS * p;
-        const int x = q >> 3, kp = q & 7;                    // 8 lanes = one row's 16 k = 128 contiguous bytes
-        s.a[p] = *reinterpret_cast<const f64x2*>(A + (long)x * lda + k0 + 2 * kp);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int q = tid + WIDE_THREADS * p;
-        const int k = q >> 7, c2 = q & 127;                  // two wave-loads = one 2 KiB k-row
-        s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(k0 + k) * ldb + 2 * c2);
-    }
-}
-
-__device__ __forceinline__ void store_wide(const StageWide& s, double* lds, int tid) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int q = tid + WIDE_THREADS * p;
-        const int x = q >> 3, kp = q & 7;
-        *reinterpret_cast<f64x2*>(lds + x * LDS_RK + 2 * kp) = s.a[p];
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int q = tid + WIDE_THREADS * p;
-        const int k = q >> 7, c2 = q & 127;
-        *reinterpret_cast<f64x2*>(lds + WIDE_A_DOUBLES + k * LDS_LD_W + 2 * c2) = s.b[p];
-    }
-}
-
-// TRI as in gemm_k_step: A(i, k) = 0 for k > tri_k0 + i.
-template <bool TRI>
-__device__ __forceinline__ void wide_k_step(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, int kn,
-                                            int k_rel, int row0, StageWide& st, const double* a_l, const double* b_l, double* nxt,
-                                            f64x4 (&acc)[4][4], int tid) {
-    load_wide(st, A, lda, B, ldb, kn, tid);
-    double af[2][4], bf[2][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        af[0][t] = a_l[t * 16 * LDS_RK];
-        bf[0][t] = b_l[t * 16];
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int kr = kk + 1, slot = (kk + 1) & 1;
-        if (kr < 4) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[slot][t] = a_l[kr * 4 + t * 16 * LDS_RK];
-                bf[slot][t] = b_l[kr * 4 * LDS_LD_W + t * 16];
-            }
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta) {
-            if (TRI && k_rel + kk * 4 > row0 + ta * 16 + 15) continue;
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
-                acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][ta], bf[kk & 1][tb], acc[ta][tb], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (kk == 0 && !TRI) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-        }
-        if (kk == 2) store_wide(st, nxt, tid);
-    }
-}
-
-// acc: this wave's 64 x 64 block; wave w: rows (w >> 2) * 64, columns (w & 3) * 64.
-__device__ __forceinline__ void gemm_tile_128x256(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
-                                                  int k_begin, int k_end, f64x4 (&acc)[4][4], double* lds, int tri_k0) {
-    if (k_begin >= k_end) return;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 2, wc = w & 3;
-    StageWide st;
-    load_wide(st, A, lda, B, ldb, k_begin, tid);
-    store_wide(st, lds, tid);
-    __syncthreads();
-    int buf = 0;
-    const int a_off = (wr * 64 + (lane & 15)) * LDS_RK + (lane >> 4);
-    const int b_off = WIDE_A_DOUBLES + wc * 64 + (lane & 15) + (lane >> 4) * LDS_LD_W;
-    const int k_split = tri_k0 < k_end ? (tri_k0 > k_begin ? tri_k0 : k_begin) : k_end;
-    int k0 = k_begin;
-    for (; k0 < k_split; k0 += TK) {
-        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
-        wide_k_step<false>(A, lda, B, ldb, kn, 0, 0, st, lds + buf * WIDE_BUF_DOUBLES + a_off, lds + buf * WIDE_BUF_DOUBLES + b_off,
-                           lds + (buf ^ 1) * WIDE_BUF_DOUBLES, acc, tid);
-        __syncthreads();
-        buf ^= 1;
-    }
-    for (; k0 < k_end; k0 += TK) {
-        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
-        wide_k_step<true>(A, lda, B, ldb, kn, k0 - tri_k0, wr * 64, st, lds + buf * WIDE_BUF_DOUBLES + a_off,
-                          lds + buf * WIDE_BUF_DOUBLES + b_off, lds + (buf ^ 1) * WIDE_BUF_DOUBLES, acc, tid);
-        __syncthreads();
-        buf ^= 1;
-    }
-}
-
 // Accumulator element acc[ta][tb][r] of this lane is output (row, col) of the tile:
 __device__ __forceinline__ int acc_row(int ta, int r) {
     const int tid = threadIdx.x;

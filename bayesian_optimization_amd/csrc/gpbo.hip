@@ -35,10 +35,6 @@ struct EvRec {
 struct gpbo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t pstream = nullptr;          // high-priority stream of the Cholesky panel work (created on first use)
-    hipStream_t bstream = nullptr;          // bulk trailing updates beside it; CU-masked so a CU per XCD stays free for the diagonal blocks
-    std::vector<hipEvent_t> sync_ev;        // cross-stream ordering events (no timing), reused by every factorisation
-    bool lookahead = true;                  // false on the work contexts of a multi-lane likelihood sweep
     std::string err;
     int64_t info = 0;
 
@@ -142,27 +138,6 @@ namespace {
     } while (0)
 
 int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
-
-// Wait for the context's stream, but not for ever: the two-stream factorisation chains waits between hardware queues, and
-// with more processes on the GPU than hardware queue slots such a chain can stop advancing.  The caller gets an error
-// after `seconds` (the work stays enqueued; the context should be destroyed).
-int sync_bounded(gpbo_ctx* ctx, double seconds) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t e = hipStreamQuery(ctx->stream);
-        if (e == hipSuccess) return GPBO_OK;
-        if (e != hipErrorNotReady) {
-            ctx->err = std::string("stream query: ") + hipGetErrorString(e);
-            return GPBO_ERR_HIP;
-        }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
-            ctx->err = "the two-stream factorisation (GPBO_CHOL_LOOKAHEAD=1) made no progress for " + std::to_string((int)seconds) +
-                       " s: the GPU is shared with other processes; unset GPBO_CHOL_LOOKAHEAD";
-            return GPBO_ERR_HIP;
-        }
-        std::this_thread::sleep_for(std::chrono::microseconds(200));
-    }
-}
 
 hipEvent_t ev_get(gpbo_ctx* ctx) {
     if (ctx->pool_used == ctx->pool.size()) {
@@ -319,13 +294,8 @@ int chol_group(int nb, int batch) {
 // n = 32768).  The row form needs only the inverses of the 16x16 diagonal tiles, so for those panels the diagonal-block
 // kernel stops after the factor ("deferred") and k_trinv_diag forms the block inverses after the factorisation, all in
 // one launch, off the critical path.  Panels from chol_first_deferred(nb, slots) on are deferred.
-bool chol_potrf_valu() {
-    static const bool v = getenv("GPBO_POTRF_VALU") && atoi(getenv("GPBO_POTRF_VALU")) != 0;
-    return v;
-}
 int chol_first_deferred(int nb, int batch) {
     static const int trsm_rows_max = getenv("GPBO_TRSM_ROWS_MAX") ? atoi(getenv("GPBO_TRSM_ROWS_MAX")) : 128;
-    if (chol_potrf_valu()) return nb;              // the all-VALU diagonal kernel (comparison runs) always inverts in place
     if (nb == 1) return nb;                        // a single block has no panel solve: inverting in place saves a launch
     return std::max(0, nb - 1 - trsm_rows_max / std::max(1, batch));      // block rows below the panel, over all slots
 }
@@ -356,7 +326,6 @@ long syrk_quarter_max() {
 void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, int p0, int g) {
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
-    static const int potrf_threads = getenv("GPBO_POTRF_THREADS") ? atoi(getenv("GPBO_POTRF_THREADS")) : POTRF_MFMA_THREADS;
     const unsigned S = (unsigned)ctx->batch;
     if (g > 1) {
         const int h = g / 2, c0 = p0 + h;          // columns c0 .. p0 + g - 1 take panels p0 .. c0 - 1
@@ -376,10 +345,7 @@ void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, 
     }
     const int q = p0;
     const int defer = q >= chol_first_deferred(nb, ctx->batch);
-    if (chol_potrf_valu())
-        hipLaunchKernelGGL(k_potrf_diag<false>, dim3(1, 1, S), dim3(POTRF_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, 0, (int)ctx->n);
-    else
-        hipLaunchKernelGGL(k_potrf_diag<true>, dim3(1, 1, S), dim3(potrf_threads), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, defer, (int)ctx->n);
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1, 1, S), dim3(POTRF_MFMA_THREADS), 0, st, A, ld, q, ctx->Dinv, info_dev, ctx->bs, defer, (int)ctx->n);
     if (q + 1 < nb) {
         if (defer)
             hipLaunchKernelGGL(k_trsm_rows, dim3(8 * (nb - q - 1), 1, S), dim3(64), 0, st, A, ld, q, (const double*)ctx->Dinv, ctx->bs);
@@ -388,98 +354,12 @@ void chol_factor_group(hipStream_t st, gpbo_ctx* ctx, double* A, int* info_dev, 
     }
 }
 
-hipEvent_t sync_event(gpbo_ctx* ctx, size_t i) {
-    while (ctx->sync_ev.size() <= i) {
-        hipEvent_t e;
-        hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        ctx->sync_ev.push_back(e);
-    }
-    return ctx->sync_ev[i];
-}
-
-// Two-stream form (lookahead).  Bulk stream, per group g, in order: U_next(g) = group g's update of the NEXT group's
-// block columns, then U_rest(g) = its update of everything right of them.  Panel stream (high priority): F(g+1) as
-// soon as U_next(g) is done, i.e. beside U_rest(g); U_next(g+1) waits for F(g+1).  Every update of a tile is issued on
-// the bulk stream in factorisation order; the panel stream touches only the block columns of its own group.
-//
-// Where the diagonal-block kernel runs meanwhile (measured at n = 32768, trailing update in flight): sharing a CU with
-// a tile workgroup it takes 0.7 ms instead of 0.19 ms (1.4 ms when held to the 256 registers that fit beside a tile
-// wave), and the panel stream becomes the critical path; asking for a CU of its own it waits for the whole update
-// (1.6 ms, up to 12 ms) unless the bulk stream's CU mask leaves CUs free.  A mask that leaves out one CU per XCD
-// costs the bulk stream 13-19 % (the workgroup distributor deals evenly over shader engines, the short one sets
-// the pace) and is still the fastest combination at every size measured: masked bulk stream, exclusive diagonal
-// kernel.  GPBO_CHOL_MASK=0 selects an unmasked bulk stream.
-int launch_cholesky_lookahead(gpbo_ctx* ctx, double* A, int* info_dev) {
-    const long ld = ctx->n_pad;
-    const int nb = (int)ctx->nb;
-    bool masked = true;
-    if (const char* e = getenv("GPBO_CHOL_MASK")) masked = atoi(e) != 0;
-    if (!ctx->pstream) {
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));     // hi = numerically lowest = greatest priority
-        HIPCHK(hipStreamCreateWithPriority(&ctx->pstream, hipStreamNonBlocking, hi));
-    }
-    if (masked && !ctx->bstream) {
-        hipDeviceProp_t pr;
-        HIPCHK(hipGetDeviceProperties(&pr, ctx->device));
-        std::vector<uint32_t> mask((pr.multiProcessorCount + 31) / 32, 0xffffffffu);
-        mask[0] &= ~0xffu;                                     // mask bits are dealt round-robin over the 8 XCDs: one CU of each
-        if (hipExtStreamCreateWithCUMask(&ctx->bstream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            HIPCHK(hipStreamCreateWithFlags(&ctx->bstream, hipStreamNonBlocking));
-        }
-    }
-    hipStream_t B = masked ? ctx->bstream : ctx->stream, P = ctx->pstream;
-    size_t ne = 0;
-    hipEvent_t ev = sync_event(ctx, ne++);
-    HIPCHK(hipEventRecord(ev, ctx->stream));
-    HIPCHK(hipStreamWaitEvent(P, ev, 0));
-    if (masked) HIPCHK(hipStreamWaitEvent(B, ev, 0));
-    const int G = chol_group(nb, ctx->batch);
-    for (int p0 = 0; p0 < nb; p0 += G) {
-        const int g = std::min(G, nb - p0);
-        chol_factor_group(P, ctx, A, info_dev, p0, g);
-        const int c1 = p0 + g;                      // first block right of the group
-        const int T = nb - c1;
-        if (T <= 0) break;
-        ev = sync_event(ctx, ne++);                 // F(g) done
-        HIPCHK(hipEventRecord(ev, P));
-        HIPCHK(hipStreamWaitEvent(B, ev, 0));
-        const int gn = std::min(G, T);              // width of the next group
-        hipLaunchKernelGGL(k_syrk_update<false>, dim3(gn, T), dim3(GEMM_THREADS), 0, B, A, ld, c1, c1, p0 * PB, g * PB, ctx->bs);
-        ev = sync_event(ctx, ne++);                 // U_next(g) done: the next group's columns are up to date
-        HIPCHK(hipEventRecord(ev, B));
-        HIPCHK(hipStreamWaitEvent(P, ev, 0));
-        const int T2 = T - gn;
-        if (T2 > 0)
-            hipLaunchKernelGGL(k_syrk_update<true>, dim3((unsigned)(T2 * (T2 + 1) / 2)), dim3(GEMM_THREADS), 0, B, A, ld, c1 + gn,
-                               c1 + gn, p0 * PB, g * PB, ctx->bs);
-    }
-    ev = sync_event(ctx, ne++);
-    HIPCHK(hipEventRecord(ev, P));
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
-    if (masked) {
-        ev = sync_event(ctx, ne++);
-        HIPCHK(hipEventRecord(ev, B));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
-    }
-    return GPBO_OK;
-}
-
 int launch_cholesky(gpbo_ctx* ctx, double* A, int* info_dev) {
     Scope s(ctx, T_CHOL);
     const long ld = ctx->n_pad;
     const int nb = (int)ctx->nb;
     const int G = chol_group(nb, ctx->batch);
-    // The two-stream form is opt-in (GPBO_CHOL_LOOKAHEAD=1): it is 10-25 % faster from n = 16384 up with the GPU to
-    // itself, but with other processes on the same GPU (two ranks and a parent sharing one card) every cross-stream
-    // wait took ~0.5 s and progress then stopped: with more user queues than hardware queue slots the scheduler
-    // time-slices the queues, and a chain of waits between queues advances one slice at a time.
-    bool la = false;
-    if (const char* e = getenv("GPBO_CHOL_LOOKAHEAD")) la = atoi(e) != 0 && ctx->lookahead && nb > 3 * G && ctx->batch == 1;
-    if (la) {
-        CHK(launch_cholesky_lookahead(ctx, A, info_dev));
-    } else {
+    {
         for (int p0 = 0; p0 < nb; p0 += G) {
             const int g = std::min(G, nb - p0);
             chol_factor_group(ctx->stream, ctx, A, info_dev, p0, g);
@@ -557,7 +437,6 @@ int launch_trsv(gpbo_ctx* ctx, const double* L, double eps_val, const double* ep
         std::vector<double> flags(S, 0.0);
         HIPCHK(hipMemcpy2DAsync(flags.data(), sizeof(double), ctx->params + P_REFINE, std::max<size_t>(ctx->bs.par, 1) * sizeof(double),
                                 sizeof(double), S, hipMemcpyDeviceToHost, ctx->stream));
-        if (getenv("GPBO_CHOL_LOOKAHEAD") && atoi(getenv("GPBO_CHOL_LOOKAHEAD")) != 0) CHK(sync_bounded(ctx, 120.0));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         bool any = false;
         for (double f : flags) any = any || f != 0.0;
@@ -655,8 +534,6 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     timing_begin(ctx);
     const int nkc = (int)((ctx->n_pad + ctx->kc - 1) / ctx->kc);
     const int nb = (int)ctx->nb;
-    int mode = 2;   // tile engine scheduling: priority raise over the MFMA bursts + fragment prefetch
-    if (const char* e = getenv("GPBO_TRMM_MODE")) mode = atoi(e);
     double trmm_launches = 0;
     double ms[T_NCAT], cnt[T_NCAT], ms_acc[T_NCAT];
     for (int i = 0; i < T_NCAT; ++i) ms_acc[i] = 0;
@@ -692,27 +569,13 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                 const int nj = (int)(cols / TN);
                 int cg = std::min(nj, 128);   // column blocks per tile-order group
                 if (const char* e = getenv("GPBO_TRMM_COLGROUP")) cg = std::max(1, std::min(nj, atoi(e)));
-                static const bool wide = getenv("GPBO_TRMM_WIDE") && atoi(getenv("GPBO_TRMM_WIDE")) != 0;
-                if (wide) {
-                    const int nj2 = (int)(cols / WIDE_N);
-                    int cg2 = std::min(nj2, 64);
-                    if (const char* e = getenv("GPBO_TRMM_COLGROUP")) cg2 = std::max(1, std::min(nj2, atoi(e)));
-                    if (keep_v)
-                        hipLaunchKernelGGL(k_trmm_sumsq_wide<true>, dim3((unsigned)(nb * nj2)), dim3(WIDE_THREADS), 0, ctx->stream,
-                                           (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
-                                           ctx->partial, nb, nj2, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n, cg2);
-                    else
-                        hipLaunchKernelGGL(k_trmm_sumsq_wide<false>, dim3((unsigned)(nb * nj2)), dim3(WIDE_THREADS), 0, ctx->stream,
-                                           (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
-                                           ctx->partial, nb, nj2, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0, cg2);
-                } else if (keep_v)
-                    hipLaunchKernelGGL((mode == 2 ? k_trmm_sumsq<true, 2> : mode == 1 ? k_trmm_sumsq<true, 1> : k_trmm_sumsq<true, 0>), dim3((unsigned)(nb * nj)),
-                                       dim3(GEMM_THREADS), 0, ctx->stream,
+                // tile engine mode 2: priority raised over each MFMA burst, LDS fragments requested one k-substep ahead
+                if (keep_v)
+                    hipLaunchKernelGGL((k_trmm_sumsq<true, 2>), dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n, cg);
                 else
-                    hipLaunchKernelGGL((mode == 2 ? k_trmm_sumsq<false, 2> : mode == 1 ? k_trmm_sumsq<false, 1> : k_trmm_sumsq<false, 0>), dim3((unsigned)(nb * nj)),
-                                       dim3(GEMM_THREADS), 0, ctx->stream,
+                    hipLaunchKernelGGL((k_trmm_sumsq<false, 2>), dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0, cg);
                 trmm_launches += 1;
@@ -753,12 +616,7 @@ template <int D>
 void launch_sweep_t(gpbo_ctx* ctx) {
     // two candidates per thread when every row of V starts 16-byte aligned (hipMalloc aligns the base; pitch = m)
     // the launch's first `extra` workgroups write the new row of W and the enlarged alpha (columns 0 .. n)
-    static const bool in_sweep = [] { const char* e = getenv("GPBO_APPEND_IN_SWEEP"); return !(e && e[0] == '0'); }();
-    const int extra = in_sweep ? (int)((ctx->n + 1 + 255) / 256) : 0;
-    if (!in_sweep)
-        hipLaunchKernelGGL(k_append_wrow_alpha, dim3((unsigned)((ctx->n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufW,
-                           (long)ctx->n_pad, (int)ctx->n, (const double*)ctx->lvec, (const double*)ctx->scal, (const double*)ctx->zfw,
-                           ctx->alpha1, ctx->alpha);
+    const int extra = (int)((ctx->n + 1 + 255) / 256);
     if (ctx->m % 2 == 0)
         hipLaunchKernelGGL((k_append_sweep<D, 2>), dim3((unsigned)((ctx->m / 2 + 255) / 256 + extra)), dim3(256), 0, ctx->stream,
                            (const double*)ctx->Xs, (long)ctx->m, ctx->d, (const double*)ctx->xnew_dev, (const double*)ctx->params,
@@ -930,7 +788,7 @@ int acquire_impl(gpbo_ctx* ctx, int acq, double kappa, int mode, double incumben
     double ms[T_NCAT], cnt[T_NCAT];
     timing_collect(ctx, ms, cnt);
     ctx->tm.acquire_ms = ms[T_ACQ];
-    if (r.best_i == INT64_MAX) r.best_i = 0;   // all NaN / -inf: numpy.argmax would also give the first element
+    if (r.best_i == INT64_MAX) r.best_i = 0;   // (no candidate at all; a NaN or -inf value is picked by its index like any other)
     if (argmax_out) *argmax_out = r.best_i;
     if (best_out) *best_out = r.best;
     return GPBO_OK;
@@ -1052,12 +910,6 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     for (void* p : {(void*)ctx->lb_xraw, (void*)ctx->lb_th, (void*)ctx->lb_sg, (void*)ctx->lb_nll, (void*)ctx->lb_grad,
                     (void*)ctx->lb_info, (void*)ctx->lane_gpart, (void*)ctx->lane_slot})
         if (p) hipFree(p);
-    for (hipStream_t st : {ctx->pstream, ctx->bstream})
-        if (st) {
-            hipStreamSynchronize(st);
-            hipStreamDestroy(st);
-        }
-    for (hipEvent_t e : ctx->sync_ev) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1099,7 +951,8 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     ctx->kernel = kernel;
     ctx->variant = variant;
     ctx->sigmaY = sigmaY;
-    ctx->eps = (sigmaY == 0) ? 1e-15 * (double)n : sigmaY * sigmaY;   // BayesOpt_v4.ipynb:138-141
+    // BayesOpt_v4.ipynb:138-141; the MATLAB two-factor form uses eps * length(K) (GP/BayesOpt_v3.m:343,352)
+    ctx->eps = (sigmaY == 0) ? (variant == GPBO_VARIANT_M3 ? 2.220446049250313e-16 : 1e-15) * (double)n : sigmaY * sigmaY;
     ctx->theta.assign(theta, theta + d);
     ctx->info = 0;
 
@@ -1135,6 +988,9 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
                 // the MATLAB form takes alpha from the SECOND factor (GP/BayesOpt_v3.m:352-356): Mu = (theta1 Ks0) (theta1 K0 + eps)^-1 y
                 Scope s2(ctx, T_TRSV);
                 CHK(launch_trsv_vec(ctx, ctx->bufB, ctx->yv, ctx->alpha, false, nullptr));
+                // ... and reports -logL from that alpha and the second factor's diagonal (:362)
+                hipLaunchKernelGGL(k_nll_second_factor, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bufB, (long)n_pad,
+                                   (const double*)ctx->yv, (const double*)ctx->alpha, (int)n, ctx->params);
             }
             CHK(launch_inverse(ctx, ctx->bufB, ctx->bufW, ctx->bufA));
             ctx->bufL = ctx->bufB;
@@ -1148,8 +1004,6 @@ int gpbo_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t
     int info = 0;
     HIPCHK(hipMemcpyAsync(par_out, ctx->params, sizeof(par_out), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (getenv("GPBO_CHOL_LOOKAHEAD") && atoi(getenv("GPBO_CHOL_LOOKAHEAD")) != 0)
-        CHK(sync_bounded(ctx, 30.0 + 1e-12 * (double)n * (double)n * (double)n));      // generous: 30 s + 1 s per Tflop of n^3
     HIPCHK(hipStreamSynchronize(ctx->stream));
     double ms[T_NCAT], cnt[T_NCAT];
     timing_collect(ctx, ms, cnt);
@@ -1276,6 +1130,15 @@ int gpbo_model_scalars(gpbo_ctx* ctx, double* theta1_out, double* nll_out, doubl
     if (nll_out) *nll_out = ctx->nll;
     if (y_max_out) *y_max_out = ctx->y_max;
     if (n_out) *n_out = ctx->n;
+    return GPBO_OK;
+}
+
+int gpbo_shape(gpbo_ctx* ctx, int64_t* n_out, int32_t* d_out, int64_t* m_out, int64_t* candidate_rows_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (n_out) *n_out = ctx->n;
+    if (d_out) *d_out = ctx->d;
+    if (m_out) *m_out = ctx->m;
+    if (candidate_rows_out) *candidate_rows_out = ctx->xs_rows;
     return GPBO_OK;
 }
 
@@ -1433,7 +1296,7 @@ int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int64_t n_pad_in, int32_t d, int3
     ctx->kernel = kernel;
     ctx->variant = variant;
     ctx->sigmaY = sigmaY;
-    ctx->eps = (sigmaY == 0) ? 1e-15 * (double)n : sigmaY * sigmaY;
+    ctx->eps = (sigmaY == 0) ? (variant == GPBO_VARIANT_M3 ? 2.220446049250313e-16 : 1e-15) * (double)n : sigmaY * sigmaY;
     return GPBO_OK;
 }
 
@@ -1900,7 +1763,6 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         for (int l = 0; l < lanes && l < (int)ctx->lml_lanes.size(); ++l) lane[l] = ctx->lml_lanes[l];
     auto fail_hip = [&](const char* what, hipError_t e) {
         ctx->err = std::string(what) + ": " + hipGetErrorString(e);
-        ctx->lookahead = true;
         return GPBO_ERR_HIP;
     };
 #define LCHK(expr)                                         \
@@ -1943,8 +1805,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
         if (!lane[l]) {
             if (gpbo_create(ctx->device, &lane[l]) != GPBO_OK) {
                 ctx->err = "lml_batch: could not create a work context";
-                ctx->lookahead = true;
-                return GPBO_ERR_HIP;
+                        return GPBO_ERR_HIP;
             }
             ctx->lml_lanes.push_back(lane[l]);
         }
@@ -1954,7 +1815,6 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             ctx->err = c->err;
             return st;
         }
-        c->lookahead = (lanes == 1) && !use_graph;   // several lanes already overlap each other's panel work
         c->fitted = false;                           // the model buffers are work space here
         c->have_posterior = false;
         c->have_acq = false;
@@ -2059,8 +1919,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             if (g) hipGraphDestroy(g);
             if (st != GPBO_OK) {
                 if (c != ctx) ctx->err = c->err;
-                ctx->lookahead = true;
-                return st;
+                        return st;
             }
             if (e != hipSuccess) return fail_hip("lml_batch: graph capture", e);
             c->lane_graph_key = k;
@@ -2079,8 +1938,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, i
             if (st != GPBO_OK) {
                 if (c != ctx) ctx->err = c->err;
                 for (int l = 0; l < lanes; ++l) hipStreamSynchronize(lane[l]->stream);
-                ctx->lookahead = true;
-                return st;
+                        return st;
             }
             // the event pool of a lane grows with every launch sequence; recycle it when the lane's stream is idle enough
             if (c->pool_used > 4096) {
@@ -2142,12 +2000,20 @@ hipError_t static_scratch(int device, double** out) {
 
 extern "C" int gpbo_acquire_static(int32_t device, void* stream, const double* mu_dev, const double* var_dev, int64_t m,
                                    int32_t acq, double kappa, int32_t incumbent_mode, double incumbent, double* acq_out_dev,
-                                   int64_t* argmax_out, double* best_out, double* mu_max_out) {
+                                   double* result_dev, int64_t* argmax_out, double* best_out, double* mu_max_out) {
     if (!mu_dev || !var_dev || !acq_out_dev) return GPBO_ERR_BAD_ARG;
     if (m <= 0 || m > STATIC_MAX_M) return GPBO_ERR_BAD_ARG;                 // beyond the stated maximum: rejected, nothing launched
     if (acq < 0 || acq > 2) return GPBO_ERR_BAD_ARG;
     if (incumbent_mode != GPBO_INCUMBENT_MAX_MU && incumbent_mode != GPBO_INCUMBENT_GIVEN) return GPBO_ERR_BAD_ARG;   // no model here: no max(yTrain)
     if (device < 0 || device >= STATIC_MAX_DEVICES) return GPBO_ERR_BAD_ARG;
+    // the caller's current device is put back on every way out (a torch caller may be working on another GPU)
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } guard;
+    if (hipGetDevice(&guard.prev) != hipSuccess) guard.prev = -1;
     if (hipSetDevice(device) != hipSuccess) return GPBO_ERR_HIP;
     double* sp = nullptr;
     if (static_scratch(device, &sp) != hipSuccess) return GPBO_ERR_HIP;
@@ -2174,13 +2040,15 @@ extern "C" int gpbo_acquire_static(int32_t device, void* stream, const double* m
                        part_v, part_i);
     hipLaunchKernelGGL(k_argmax_stage, dim3(1), dim3(256), 0, st, (const double*)part_v, (const long*)part_i, (long)blocks, best_v,
                        best_i);
+    if (result_dev) hipLaunchKernelGGL(k_copy4, dim3(1), dim3(64), 0, st, result_dev, (const double*)inc);
     if (hipGetLastError() != hipSuccess) return GPBO_ERR_HIP;
+    if (!argmax_out && !best_out && !mu_max_out) return GPBO_OK;      // launches only: legal on a capturing stream
     double h[4] = {0, 0, 0, 0};      // incumbent, max(mu), best value, best index (bit pattern of an int64)
     if (hipMemcpyAsync(h, inc, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return GPBO_ERR_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return GPBO_ERR_HIP;
     long bi;
     memcpy(&bi, &h[3], sizeof(bi));
-    if (bi == INT64_MAX) bi = 0;     // all NaN / -inf: numpy.argmax would also give the first element
+    if (bi == INT64_MAX) bi = 0;     // (no candidate at all; a NaN or -inf value is picked by its index like any other)
     if (argmax_out) *argmax_out = bi;
     if (best_out) *best_out = h[2];
     if (mu_max_out) *mu_max_out = h[1];

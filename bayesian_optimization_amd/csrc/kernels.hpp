@@ -154,232 +154,20 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict_
 // ---------------------------------------------------------------------------------------
 
 // Diagonal block p of the blocked factorisation: Cholesky factor of the 128x128 block and its inverse in one
-// workgroup, both on a packed copy of the lower triangle in LDS.  Two forms: all-VALU, 256 threads (potrf128_lds: eight
-// 16-column panels; trinv128_lds: recursive doubling; 0.12 ms per block, kept for same-machine comparison) and the MFMA
-// form further down (potrf128_mfma / trinv128_mfma, 1024 threads, 0.034 ms), which the one-workgroup likelihood kernel
-// uses as well.  A column-by-column elimination of the whole block on register tiles (256 barriers) took 0.19 ms.
+// workgroup (1024 threads), both on a packed copy of the lower triangle in LDS (row r starts at r (r + 1) / 2), on the
+// MFMA routines below (potrf128_mfma / trinv128_mfma), which the one-workgroup likelihood kernel uses as well.
 // Writes L (lower, zeros above) back into A and inv(L) (lower, zeros above) into Dinv.
 // info: first failing 1-based global row (pivot <= 0 or NaN), set once.
-constexpr int POTRF_THREADS = 256;
-// The inverse phase reads L from a packed lower-triangular LDS copy (row r starts at r (r + 1) / 2); a wave reads four
-// distinct addresses per access (one per tile row): broadcasts, no bank conflicts.  The LDS request is padded to
-// 94 KB: the kernel is latency bound and runs 4x slower when its waves share SIMDs with MFMA waves, so it must not
-// fit on a CU that holds a tile-engine workgroup (72 KB of 160).
+constexpr int POTRF_THREADS = 256;      // workgroup of the one-workgroup likelihood / descent routines for small n
 __device__ __forceinline__ constexpr int tri_off(int r) { return r * (r + 1) / 2; }
 constexpr int POTRF_LDS_PACKED = PB * (PB + 1) / 2;     // 8256 doubles
-// Cholesky factor of the 128x128 block held packed in LDS (M, row r at tri_off(r)), in place, right-looking over eight
-// 16-column panels: (a) the 16x16 diagonal block by ONE wave (row i in lane i & 15, four columns per lane, the pivot
-// column exchanged through LDS; no workgroup barrier inside), (b) the rows below by substitution, one thread per row,
-// (c) the rank-16 update of the trailing triangle on 4x4 register blocks.  24 barriers instead of the 128 of a
-// column-by-column elimination over the whole block.  *failp (LDS, preset to -1) receives the first column whose
-// pivot is <= 0 or NaN.  All 256 threads must call it; ends on a barrier.
 #ifdef GPBO_STAMPS
 __device__ long long g_stamps[64];
 #define GPBO_STAMP(i, acc) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); if (acc) g_stamps[i] += t_ - g_stamps[63]; g_stamps[63] = t_; } } while (0)
 #else
 #define GPBO_STAMP(i, acc) do { } while (0)
 #endif
-__device__ __forceinline__ void potrf128_lds(double* __restrict__ M, int* __restrict__ failp) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int jb = 0; jb < 8; ++jb) {
-        const int c0 = 16 * jb;
-        GPBO_STAMP(0, 0);
-        if (w == 0) {
-            const int i = lane & 15, g = lane >> 4;
-            double v[4];
-            int fail = -1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (4 * g + e <= i) ? M[tri_off(c0 + i) + c0 + 4 * g + e] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (g == (j >> 2) && i >= j) M[tri_off(c0 + i) + c0 + j] = v[j & 3];      // publish column j as it stands
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // all six reads are issued together; the square root works on the first while the rest arrive
-                const double piv = M[tri_off(c0 + j) + c0 + j];
-                const double rij = M[tri_off(c0 + (i > j ? i : j)) + c0 + j];
-                double rc[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = 4 * g + e;
-                    rc[e] = M[tri_off(c0 + (c > j ? c : j)) + c0 + j];
-                }
-                if (!(piv > 0.0) && fail < 0) fail = c0 + j;
-                // 1/sqrt from the hardware estimate and two Newton steps, sqrt as piv * (1/sqrt) with one correction:
-                // a dozen dependent operations instead of the ~45 of a correctly rounded sqrt followed by a division
-                double rd = __builtin_amdgcn_rsq(piv);
-                rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
-                rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
-                double d = piv * rd;
-                d = fma(0.5 * rd, fma(-d, d, piv), d);
-                const double lij = (i > j) ? rij * rd : 0.0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = 4 * g + e;
-                    if (c > j && c <= i) v[e] = fma(-lij, rc[e] * rd, v[e]);
-                }
-                if (g == (j >> 2)) {
-                    if (i == j) v[j & 3] = d;
-                    else if (i > j) v[j & 3] = lij;
-                }
-                __builtin_amdgcn_wave_barrier();     // every lane has read column j before the next publish overwrites LDS
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * g + e <= i) M[tri_off(c0 + i) + c0 + 4 * g + e] = v[e];
-            if (lane == 0 && fail >= 0 && *failp < 0) *failp = fail;
-        }
-        __syncthreads();
-        GPBO_STAMP(1, 1);
-        const int r1 = c0 + 16;                      // first row below the panel's diagonal block
-        const int nrows = PB - r1;
-        if (tid < nrows) {                           // x L11^T = b, row r1 + tid
-            const int r = r1 + tid;
-            double x[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double sacc = M[tri_off(r) + c0 + j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) sacc = fma(-x[k], M[tri_off(c0 + j) + c0 + k], sacc);
-                x[j] = sacc / M[tri_off(c0 + j) + c0 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) M[tri_off(r) + c0 + j] = x[j];
-        }
-        __syncthreads();
-        GPBO_STAMP(2, 1);
-        const int n4 = nrows >> 2;                   // trailing triangle in 4x4 blocks
-        const int nblk = n4 * (n4 + 1) / 2;
-        for (int blk = tid; blk < nblk; blk += POTRF_THREADS) {
-            int bi, bj;
-            tri_decode(blk, bi, bj);
-            const int ra = r1 + 4 * bi, qa = r1 + 4 * bj;
-            double acc[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                double lr[4], lc[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    lr[a] = M[tri_off(ra + a) + c0 + k];
-                    lc[a] = M[tri_off(qa + a) + c0 + k];
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(lr[a], lc[b], acc[a][b]);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (qa + b <= ra + a) M[tri_off(ra + a) + qa + b] -= acc[a][b];
-        }
-        __syncthreads();
-        GPBO_STAMP(3, 1);
-    }
-}
-
-// Inverse of the 128x128 lower-triangular block held packed in LDS (M, row r at tri_off(r)), in place, by recursive
-// doubling: the eight 16x16 diagonal blocks by substitution (one thread per column), then three levels
-//   W[B,A] = -W[B,B] (L[B,A] W[A,A])      with half sizes 16, 32, 64,
-// each as two small triangular products on register blocks, the intermediate product in T.  About ten barriers
-// instead of the 128 sequential steps of an elimination.  All 256 threads must call it; ends on a barrier.
-template <int S, int BR, int BC>
-__device__ __forceinline__ void trinv_level(double* __restrict__ M, double* __restrict__ T) {
-    constexpr int P = PB / (2 * S);
-    constexpr int NBR = S / BR, NBC = S / BC;
-    constexpr int TOTAL = P * NBR * NBC;
-    static_assert(TOTAL <= POTRF_THREADS, "one register block per thread");
-    const int tid = threadIdx.x;
-    const bool act = tid < TOTAL;
-    const int p = tid / (NBR * NBC), rem = tid % (NBR * NBC);
-    const int i0 = (rem / NBC) * BR, j0 = (rem % NBC) * BC;
-    const int a0 = 2 * p * S, b0 = a0 + S;
-    double* Tp = T + p * S * (S + 1);
-    double acc[BR][BC];
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < BR; ++r)
-#pragma unroll
-            for (int c = 0; c < BC; ++c) acc[r][c] = 0.0;
-        for (int k = j0; k < S; ++k) {           // T = L[B,A] W[A,A], W[A,A] lower: k >= j
-            double lv[BR], wv[BC];
-#pragma unroll
-            for (int r = 0; r < BR; ++r) lv[r] = M[tri_off(b0 + i0 + r) + a0 + k];
-#pragma unroll
-            for (int c = 0; c < BC; ++c) {
-                const double w = M[tri_off(a0 + k) + a0 + j0 + c];
-                wv[c] = (k >= j0 + c) ? w : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < BR; ++r)
-#pragma unroll
-                for (int c = 0; c < BC; ++c) acc[r][c] = fma(lv[r], wv[c], acc[r][c]);
-        }
-#pragma unroll
-        for (int r = 0; r < BR; ++r)
-#pragma unroll
-            for (int c = 0; c < BC; ++c) Tp[(i0 + r) * (S + 1) + j0 + c] = acc[r][c];
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-        for (int r = 0; r < BR; ++r)
-#pragma unroll
-            for (int c = 0; c < BC; ++c) acc[r][c] = 0.0;
-        for (int k = 0; k < i0 + BR; ++k) {      // W[B,A] = -W[B,B] T, W[B,B] lower: k <= i
-            double wv[BR], tv[BC];
-#pragma unroll
-            for (int r = 0; r < BR; ++r) {
-                const double w = M[tri_off(b0 + i0 + r) + b0 + k];
-                wv[r] = (k <= i0 + r) ? w : 0.0;
-            }
-#pragma unroll
-            for (int c = 0; c < BC; ++c) tv[c] = Tp[k * (S + 1) + j0 + c];
-#pragma unroll
-            for (int r = 0; r < BR; ++r)
-#pragma unroll
-                for (int c = 0; c < BC; ++c) acc[r][c] = fma(wv[r], tv[c], acc[r][c]);
-        }
-        // L[B,A] was last read before the barrier above; step 2 reads only W[B,B] and T
-#pragma unroll
-        for (int r = 0; r < BR; ++r)
-#pragma unroll
-            for (int c = 0; c < BC; ++c) M[tri_off(b0 + i0 + r) + a0 + j0 + c] = -acc[r][c];
-    }
-    __syncthreads();
-}
-
 constexpr int TRINV_T_DOUBLES = 64 * 65;
-__device__ __forceinline__ void trinv128_lds(double* __restrict__ M, double* __restrict__ T) {
-    const int tid = threadIdx.x;
-    double x[16];
-    const int q = (tid >> 4) & 7, c = tid & 15, base = 16 * q;
-    if (tid < 128) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) sacc = fma(-M[tri_off(base + i) + base + k], x[k], sacc);
-            x[i] = sacc / M[tri_off(base + i) + base + i];
-        }
-    }
-    __syncthreads();
-    if (tid < 128) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (i >= c) M[tri_off(base + i) + base + c] = x[i];
-    }
-    __syncthreads();
-    trinv_level<16, 1, 4>(M, T);
-    trinv_level<32, 2, 4>(M, T);
-    trinv_level<64, 4, 4>(M, T);
-}
 
 // ---------------------------------------------------------------------------------------
 // MFMA form of the diagonal block (potrf128_mfma + trinv128_mfma): the block lives packed in LDS as before, but
@@ -605,16 +393,15 @@ __device__ __forceinline__ int data_tiles(int n, int p) {
     return t < 1 ? 1 : (t > 8 ? 8 : t);
 }
 
-// defer (MFMA form only): stop after the factor; the inverses of the eight 16x16 diagonal tiles go into the diagonal
+// defer: stop after the factor; the inverses of the eight 16x16 diagonal tiles go into the diagonal
 // tiles of the block's Dinv (all k_trsm_rows needs), the inverse of the whole block is left to k_trinv_diag.
-template <bool MFMA>
 __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
                                                 int* __restrict__ info, double* __restrict__ S, bool defer, int ntl) {
     __shared__ int fail_s;
     const int tid = threadIdx.x;
     double* blk = A + (long)p * PB * ld + (long)p * PB;
     double* Tbuf = S + POTRF_LDS_PACKED;
-    double* Wi8 = Tbuf + TRINV_T_DOUBLES;          // only the MFMA form has (and uses) this space
+    double* Wi8 = Tbuf + TRINV_T_DOUBLES;
     GPBO_STAMP(8, 0);
     if (tid == 0) fail_s = -1;
     // lower triangle -> packed LDS.  Eight requests per thread go out before the first is waited for (with 1024 threads
@@ -641,8 +428,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     }
     __syncthreads();
     GPBO_STAMP(4, 1);
-    if (MFMA) potrf128_mfma(S, Wi8, &fail_s, ntl);
-    else potrf128_lds(S, &fail_s);
+    potrf128_mfma(S, Wi8, &fail_s, ntl);
     GPBO_STAMP(5, 1);
     if (tid == 0 && fail_s >= 0) atomicCAS(info, 0, p * PB + fail_s + 1);
     for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {      // L -> global, zeros above the diagonal
@@ -653,7 +439,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
         *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
     }
     double* dinv = Dinv + (long)p * PB * PB;
-    if (MFMA && defer) {
+    if (defer) {
         for (int idx = tid; idx < 8 * 256; idx += blockDim.x) {
             const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
             dinv[(16 * b + r) * PB + 16 * b + c] = (c <= r) ? Wi8[b * LEAF_DOUBLES + r * LEAF_P + c] : 0.0;
@@ -663,8 +449,7 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     }
     __syncthreads();
     GPBO_STAMP(6, 1);
-    if (MFMA) trinv128_mfma(S, Wi8, Tbuf, ntl);
-    else trinv128_lds(S, Tbuf);
+    trinv128_mfma(S, Wi8, Tbuf, ntl);
     GPBO_STAMP(7, 1);
     for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
         const int r = idx >> 6, c = (idx & 63) * 2;
@@ -676,17 +461,16 @@ __device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld,
     GPBO_STAMP(9, 1);
 }
 
-// The LDS request (packed L, the product buffer of the inverse and the tile inverses: 99 KB / 116 KB) keeps every
+// The LDS request (packed L, the product buffer of the inverse and the tile inverses: 116 KB) keeps every
 // tile-engine workgroup (72 KB of 160) off the CU: the kernel is latency bound and runs 4x slower when its waves share
-// SIMDs with MFMA waves.  MFMA = false: the earlier all-VALU form, kept for same-machine comparison (GPBO_POTRF_VALU=1).
+// SIMDs with MFMA waves.
 constexpr int POTRF_MFMA_THREADS = 1024;        // 16 waves: the MFMA phases are LDS-latency bound, four waves per SIMD hide it
-template <bool MFMA>
-__global__ __launch_bounds__(MFMA ? POTRF_MFMA_THREADS : POTRF_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
+__global__ __launch_bounds__(POTRF_MFMA_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
                                                               double* __restrict__ Dinv, int* __restrict__ info, BatchStride bs,
                                                               int defer, int n) {
-    __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + (MFMA ? 8 * LEAF_DOUBLES : 0)];
-    potrf_diag_body<MFMA>(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S, defer != 0,
-                          data_tiles(n, p));
+    __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES];
+    potrf_diag_body(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S, defer != 0,
+                    data_tiles(n, p));
 }
 
 // Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T
@@ -1422,6 +1206,31 @@ __global__ __launch_bounds__(256) void k_fit_scalars(const double* __restrict__ 
     for (int i = tid; i < n_pad; i += 256) alpha_out[i] = (i < n) ? (variant != 1 ? alpha1[i] / theta1 : alpha1[i]) : 0.0;
 }
 
+// -logL as the MATLAB two-factor form reports it (GP/BayesOpt_v3.m:362): n/2 (log 2 pi + 1) + n/2 log(y.alpha2 / n) +
+// sum log diag L2, with alpha2 and L2 of the SECOND factorisation (theta1 K0 + eps).  One workgroup, fixed order.
+__global__ __launch_bounds__(256) void k_nll_second_factor(const double* __restrict__ L2, long ld, const double* __restrict__ y,
+                                                           const double* __restrict__ alpha2, int n, double* __restrict__ params) {
+    __shared__ double r1[256];
+    __shared__ double r2[256];
+    const int tid = threadIdx.x;
+    double ya = 0.0, sl = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        ya += y[i] * alpha2[i];
+        sl += log(L2[(long)i * ld + i]);
+    }
+    r1[tid] = ya;
+    r2[tid] = sl;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            r1[tid] += r1[tid + o];
+            r2[tid] += r2[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) params[P_NLL] = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(r1[0] / n) + r2[0];
+}
+
 // ---------------------------------------------------------------------------------------
 // K(X*,X) chunk: Bmat[k][j] = cb * k(D(x_k, xs_j)) for k < n (0 for the pad), j over the chunk
 // (j contiguous), plus partial means  mupart[kc][j] = sum_{k in chunk kc} Bmat[k][j] * alpha[k].
@@ -1564,57 +1373,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __
     if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
 }
 
-// The same product on 128 x 256 tiles (gemm_tile_128x256; 512 threads).  nj2 = column blocks of 256.
-template <bool STORE_V>
-__global__ __launch_bounds__(WIDE_THREADS, 1) void k_trmm_sumsq_wide(const double* __restrict__ W, long ld,
-                                                                     const double* __restrict__ Bmat, long ldb,
-                                                                     double* __restrict__ partial, int nb, int nj2,
-                                                                     double* __restrict__ Vres, long ldv, long j0, long m, int v_rows,
-                                                                     int cg) {
-    const int per = nb * cg;
-    const int grp = blockIdx.x / per, r = blockIdx.x % per;
-    const int cw = min(cg, nj2 - grp * cg);
-    const int ib = nb - 1 - r / cw;
-    const int jb = grp * cg + r % cw;
-    __shared__ double lds[WIDE_LDS_DOUBLES];
-    f64x4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_128x256(W + (long)ib * PB * ld, ld, Bmat + (long)jb * WIDE_N, ldb, 0, (ib + 1) * PB, acc, lds, ib * PB);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 2, wc = w & 3;
-    if (STORE_V) {
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int row = ib * PB + wr * 64 + ta * 16 + (lane >> 4) + 4 * r4;
-                    const long col = j0 + (long)jb * WIDE_N + wc * 64 + tb * 16 + (lane & 15);
-                    if (row < v_rows && col < m) Vres[(long)row * ldv + col] = acc[ta][tb][r4];
-                }
-    }
-    double cs[4];
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-        double s = 0.0;
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) s += acc[ta][tb][r4] * acc[ta][tb][r4];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        cs[tb] = s;
-    }
-    double* red = lds;   // the tile engine ended on a barrier: LDS is free
-    if ((lane >> 4) == 0) {
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) red[wr * WIDE_N + wc * 64 + tb * 16 + lane] = cs[tb];
-    }
-    __syncthreads();
-    if (tid < WIDE_N) partial[(long)ib * ldb + (long)jb * WIDE_N + tid] = red[tid] + red[WIDE_N + tid];
-}
-
 // Trend basis of the kriging flavour (polymat, Gaussian_Process_Regression.ipynb:113-140): columns for
 // C = 1..3 inputs and degree 0..3, in the reference's column order.  Returns f(x) . beta.
 __device__ __forceinline__ double trend_eval(const double* __restrict__ x, int C, int deg, const double* __restrict__ beta) {
@@ -1663,17 +1421,20 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
 
 // ---------------------------------------------------------------------------------------
 // Reductions: max and (value, first index) argmax, two stages, deterministic.
+// Both follow NumPy on NaN: a maximum that meets a NaN is NaN (np.max, BayesOpt_v4.ipynb:193), and the argmax returns the
+// first NaN if there is one (np.argmax, :647), so a poisoned posterior surfaces instead of being masked.
+__device__ __forceinline__ double max_nan(double a, double b) { return (a > b || a != a) ? a : b; }
 // out2 (optional, single-workgroup launches): a second destination for the result (the incumbent slot of the acquisition)
 __global__ __launch_bounds__(256) void k_max_stage(const double* __restrict__ a, long m, double* __restrict__ out,
                                                    double* __restrict__ out2 = nullptr) {
     __shared__ double r[256];
     const int tid = threadIdx.x;
     double v = -INFINITY;
-    for (long i = (long)blockIdx.x * 256 + tid; i < m; i += (long)gridDim.x * 256) v = fmax(v, a[i]);
+    for (long i = (long)blockIdx.x * 256 + tid; i < m; i += (long)gridDim.x * 256) v = max_nan(v, a[i]);
     r[tid] = v;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) r[tid] = fmax(r[tid], r[tid + o]);
+        if (tid < o) r[tid] = max_nan(r[tid], r[tid + o]);
         __syncthreads();
     }
     if (tid == 0) {
@@ -1701,7 +1462,11 @@ __global__ void k_step_end(const double* __restrict__ params, const int* __restr
     if (t == 11) reinterpret_cast<long*>(res)[11] = *best_i;
 }
 
+// (v, i) goes ahead of (bv, bi): a NaN ranks above every number, equal ranks go to the lower index.  A total order, so
+// the winner does not depend on the shape of the reduction.
 __device__ __forceinline__ bool better(double v, long i, double bv, long bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
     return (v > bv) || (v == bv && i < bi);
 }
 
@@ -1858,10 +1623,10 @@ __global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict
     double inc;
     if (n_parts > 0) {
         double v = (tid < n_parts) ? inc_parts[tid] : -INFINITY;
-        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        for (int o = 32; o > 0; o >>= 1) v = max_nan(v, __shfl_xor(v, o));
         if ((tid & 63) == 0) rv[tid >> 6] = v;
         __syncthreads();
-        inc = fmax(fmax(rv[0], rv[1]), fmax(rv[2], rv[3]));
+        inc = max_nan(max_nan(rv[0], rv[1]), max_nan(rv[2], rv[3]));
         __syncthreads();                                   // rv is reused below
         if (blockIdx.x == 0 && tid == 0) {
             inc_out[0] = inc;
@@ -2743,12 +2508,6 @@ __device__ __forceinline__ void append_wrow_alpha(int blk, double* __restrict__ 
     alpha[j] = a;
 }
 
-__global__ __launch_bounds__(256) void k_append_wrow_alpha(double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
-                                                           const double* __restrict__ scal, const double* __restrict__ zfw,
-                                                           double* __restrict__ alpha1, double* __restrict__ alpha) {
-    append_wrow_alpha((int)blockIdx.x, W, ld, n, lvec, scal, zfw, alpha1, alpha);
-}
-
 // The HBM-streaming sweep: per candidate j
 //   v = (k(xs_j, x_new) - sum_{k<n} l_k V[k][j]) / d_new ;  V[n][j] = v ;  s_j += v^2 ;  mu_j += v z_new ;
 //   var_j = theta1 (1 - s_j), < 1e-60 -> 0.
@@ -2830,7 +2589,7 @@ __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__
         sres[j + c] = s;
         const double mnew = mu[j + c] + v * znew;
         mu[j + c] = mnew;
-        mx = fmax(mx, mnew);
+        mx = max_nan(mx, mnew);
         double vr = c0 - c1 * s;
         if (vr < 1e-60) vr = 0.0;
         var[j + c] = vr;
@@ -2846,10 +2605,10 @@ __global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__
     }
     // max(mu) of the workgroup's candidates (stage 1 of the reduction every iteration needs, free of a pass over mu)
     __shared__ double wm[4];
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    for (int o = 32; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) bmax[blk] = fmax(fmax(wm[0], wm[1]), fmax(wm[2], wm[3]));
+    if (threadIdx.x == 0) bmax[blk] = max_nan(max_nan(wm[0], wm[1]), max_nan(wm[2], wm[3]));
 }
 
 
@@ -2949,5 +2708,8 @@ __global__ __launch_bounds__(256) void k_uniform_splitmix(double* __restrict__ o
 
 __global__ void k_set_scalar(double* dst, double v) { *dst = v; }
 __global__ void k_copy_scalar(double* dst, const double* src) { *dst = *src; }
+__global__ void k_copy4(double* dst, const double* src) {
+    if (threadIdx.x < 4) dst[threadIdx.x] = src[threadIdx.x];
+}
 
 }  // namespace gpbo

@@ -34,16 +34,20 @@ def _exchange_device(device):
 
 
 def allreduce_max(x: float, device=None) -> float:
+    """Maximum over ranks with numpy.max's NaN rule (a NaN anywhere gives NaN): what a collective's MAX does with a NaN
+    is not specified, so the NaN travels as a flag beside the value."""
     if not _is_dist():
         return float(x)
-    t = torch.tensor([x], dtype=torch.float64, device=_exchange_device(device))
+    bad = bool(np.isnan(x))
+    t = torch.tensor([-np.inf if bad else float(x), 1.0 if bad else 0.0], dtype=torch.float64, device=_exchange_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    t = t.cpu()
+    return float('nan') if float(t[1].item()) > 0.0 else float(t[0].item())
 
 
 def global_argmax(local_best: float, local_index: int, offset: int, device=None):
-    """(best value, global index) over all ranks: maximum value, ties -> lowest global index.
-    NaN local values never win (numpy.argmax would return the first NaN; the sweep produces none)."""
+    """(best value, global index) over all ranks: maximum value, ties -> lowest global index; a NaN ranks above every
+    number, as in numpy.argmax (BayesOpt/BayesOpt_v4.ipynb:647), so the lowest NaN index wins when there is one."""
     gi = int(local_index) + int(offset)
     if not _is_dist():
         return float(local_best), gi
@@ -84,11 +88,11 @@ def global_first_at_least(gp, threshold, offset, fallback):
 def pick_best(values, indices):
     values = np.asarray(values, dtype=np.float64)
     indices = np.asarray(indices, dtype=np.int64)
-    ok = ~np.isnan(values)
-    if not ok.any():
-        return float('nan'), int(indices.min())
-    vmax = values[ok].max()
-    return float(vmax), int(indices[ok & (values == vmax)].min())
+    bad = np.isnan(values)
+    if bad.any():
+        return float('nan'), int(indices[bad].min())
+    vmax = values.max()
+    return float(vmax), int(indices[values == vmax].min())
 
 
 class _DevBuf:

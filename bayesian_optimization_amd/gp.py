@@ -87,14 +87,19 @@ class GP:
         if th.shape[0] != X.shape[1]:
             raise ValueError('theta has %d entries, xTrain %d columns' % (th.shape[0], X.shape[1]))
         t1, nll = C.c_double(), C.c_double()
-        self._check(self._lib.gpbo_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th),
-                                       float(sigmaY), int(kernel), int(variant), C.byref(t1), C.byref(nll)))
-        if X.shape[1] != self.d:
-            self._xs_rows = 0    # candidates stay resident across refits unless the column count changes
-        self.m = self._xs_rows
-        self.n, self.d = X.shape
+        try:
+            self._check(self._lib.gpbo_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th),
+                                           float(sigmaY), int(kernel), int(variant), C.byref(t1), C.byref(nll)))
+        finally:
+            self._sync_shape()   # candidates stay resident across refits unless the column count changes; also after a failed fit
         self.theta1, self.nll = t1.value, nll.value
         return self
+
+    def _sync_shape(self):
+        """n, d, m and the resident candidate rows as the library holds them (it replaces them before a fit can fail)."""
+        n, d, m, rows = C.c_int64(), C.c_int32(), C.c_int64(), C.c_int64()
+        self._lib.gpbo_shape(self._h, C.byref(n), C.byref(d), C.byref(m), C.byref(rows))
+        self.n, self.d, self.m, self._xs_rows = int(n.value), int(d.value), int(m.value), int(rows.value)
 
     def set_candidates(self, xTest):
         Xs = _f64(xTest, 2)
@@ -173,12 +178,11 @@ class GP:
             raise ValueError('xT has %d rows, yT %d' % (X.shape[0], y.shape[0]))
         beta = np.zeros(10)
         nb, cov = C.c_int32(), C.c_double()
-        self._check(self._lib.gpbo_kriging_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1],
-                                               float(np.squeeze(theta)), int(deg), L.dptr(beta), C.byref(nb), C.byref(cov)))
-        if X.shape[1] != self.d:
-            self._xs_rows = 0    # as in fit(): resident candidates survive a refit with the same column count
-        self.m = self._xs_rows
-        self.n, self.d = X.shape
+        try:
+            self._check(self._lib.gpbo_kriging_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1],
+                                                   float(np.squeeze(theta)), int(deg), L.dptr(beta), C.byref(nb), C.byref(cov)))
+        finally:
+            self._sync_shape()   # as in fit(): resident candidates survive a refit with the same column count
         self.theta1, self.nll = cov.value, float('nan')
         return beta[:nb.value].copy(), cov.value
 
@@ -246,6 +250,8 @@ class GP:
         return c.value
 
     def factor(self, want_L=True, want_alpha=True):
+        if want_L:
+            self.factor_downloads = getattr(self, 'factor_downloads', 0) + 1      # n^2 doubles device -> host each
         Lm = np.empty((self.n, self.n)) if want_L else None
         al = np.empty(self.n) if want_alpha else None
         self._check(self._lib.gpbo_get_factor(self._h, L.dptr(Lm) if want_L else None, L.dptr(al) if want_alpha else None))
@@ -295,11 +301,10 @@ class GP:
 
     def state_alloc(self, n, d, kernel, variant, sigmaY, n_pad=0):
         """n_pad: the sender's padded size (StateDesc.n_pad); 0 = round_up(n, 128)."""
-        self._check(self._lib.gpbo_state_alloc(self._h, int(n), int(n_pad), int(d), int(kernel), int(variant), float(sigmaY)))
-        if int(d) != self.d:
-            self._xs_rows = 0
-        self.m = self._xs_rows
-        self.n, self.d = int(n), int(d)
+        try:
+            self._check(self._lib.gpbo_state_alloc(self._h, int(n), int(n_pad), int(d), int(kernel), int(variant), float(sigmaY)))
+        finally:
+            self._sync_shape()
 
     def state_commit(self, y_max):
         self._check(self._lib.gpbo_state_commit(self._h, float(y_max)))

@@ -9,10 +9,15 @@ gpr_poly :197, y_kriging_v2 :228, acquisition :265.
 Deliberate differences, all at sizes/outputs no caller in the reference consumes:
   * gprfcn returns Cov as a ``DiagCov``: np.diag(Cov) / Cov.diagonal() give the (m,) variance the callers
     use (:191,:208,:806); the dense m x m matrix is never formed.  K, Ks, Kss and v (returned but unused by
-    every caller, ``_`` at :645) are lazy ``KernelHandle`` objects that build the matrix on first use.
+    every caller, ``_`` at :645) are lazy ``KernelHandle`` objects that build the matrix on first use; L and alpha
+    are lazy ``FactorHandle`` objects that download the factor / the weights from the device when somebody looks
+    at them (np.asarray, indexing, arithmetic) -- a handle that is still alive when the next gprfcn call is about to
+    overwrite the model is filled first, so it never goes stale; one that was dropped (``_``) costs nothing.
   * distmat_v2 returns a lazy list: mlefcn/kernfcn_v2 recompute distances on the device from the points.
 """
 from __future__ import annotations
+
+import weakref
 
 import numpy as np
 
@@ -73,6 +78,57 @@ class KernelHandle:
         return self._K if dtype is None else self._K.astype(dtype)
 
 
+class FactorHandle:
+    """L (n, n) or alpha (n, 1) of the model gprfcn has just fitted, still on the device: the download (n^2 doubles for
+    L: 134 MB at n = 4096) happens on first use.  Behaves as the array for np.asarray, indexing, .T and arithmetic."""
+
+    def __init__(self, gp, which, shape):
+        self._gp, self._which, self.shape = gp, which, shape
+        self._a = None
+        self.dtype = np.dtype(np.float64)
+        self.ndim = len(shape)
+
+    def _fill(self):
+        if self._a is None:
+            gp, self._gp = self._gp, None
+            if gp is None:
+                raise RuntimeError('the model this handle belongs to has been released')
+            if self._which == 'L':
+                self._a = gp.factor(want_alpha=False)[0]
+            else:
+                self._a = gp.factor(want_L=False)[1][:, None]
+        return self._a
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._fill()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, key):
+        return self._fill()[key]
+
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def T(self):
+        return self._fill().T
+
+    def __matmul__(self, other):
+        return self._fill() @ other
+
+    def __rmatmul__(self, other):
+        return other @ self._fill()
+
+
+def _settle_factor_handles(gp):
+    """Fill the factor handles of the current model that somebody still holds, before the model is overwritten."""
+    for ref in getattr(gp, '_nb_handles', ()):
+        h = ref()
+        if h is not None and h._a is None and h._gp is not None:
+            h._fill()
+    gp._nb_handles = []
+
+
 class DiagCov:
     """diag-backed posterior covariance: np.diag(Cov), Cov.diagonal() and np.sqrt(np.diag(Cov)) work;
     the dense (m, m) matrix is not available (the reference only ever reads the diagonal)."""
@@ -111,18 +167,21 @@ def gprfcn(xTest, xTrain, yTrain, theta, sigmaY):
     xTest = np.ascontiguousarray(xTest, dtype=np.float64)
     xTrain = np.ascontiguousarray(xTrain, dtype=np.float64)
     theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+    _settle_factor_handles(gp)
     gp.fit(xTrain, yTrain, theta, sigmaY)
     gp.set_candidates(xTest)
     gp.posterior()
     mu, var = gp.read()
-    Lm, alpha = gp.factor()
+    Lm = FactorHandle(gp, 'L', (gp.n, gp.n))
+    alpha = FactorHandle(gp, 'alpha', (gp.n, 1))
+    gp._nb_handles = [weakref.ref(Lm), weakref.ref(alpha)]
     token = object()
     gp._nb_token = token
     th1 = gp.theta1
     K = KernelHandle(xTrain, xTrain, theta, th1)
     Ks = KernelHandle(xTest, xTrain, theta, th1)
     Kss = KernelHandle(xTest, xTest, theta, th1)
-    return mu[:, None], DiagCov(var, gp, token), K, Ks, Kss, Lm, alpha[:, None], None
+    return mu[:, None], DiagCov(var, gp, token), K, Ks, Kss, Lm, alpha, None
 
 
 def expected_improvement(Mu, Cov, kappa):

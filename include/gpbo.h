@@ -38,8 +38,10 @@ extern "C" {
 #define GPBO_VARIANT_V4 0      /* two-factor posterior, BayesOpt_v4.ipynb:142-151 */
 #define GPBO_VARIANT_SINGLE 1  /* single factor, theta1-scaled variance, GP/BayesOptFcn_v1.m:73-83; the scaled-factor form of
                                 * GP/BayesOpt_v2.m:177-189 (L <- sqrt(theta1) L) is the same posterior analytically */
-#define GPBO_VARIANT_M3 3      /* MATLAB two-factor form, GP/BayesOpt_v3.m:343-360: variance as v4, mean with alpha taken from
-                                * the second factor, Mu = (theta1 Ks0)(theta1 K0 + eps)^-1 y (differs from v4 when sigmaY != 0) */
+#define GPBO_VARIANT_M3 3      /* MATLAB two-factor form, GP/BayesOpt_v3.m:343-362: variance as v4, mean with alpha taken from
+                                * the second factor, Mu = (theta1 Ks0)(theta1 K0 + eps)^-1 y (differs from v4 when sigmaY != 0);
+                                * jitter eps*n with MATLAB's eps = 2^-52 when sigmaY == 0 (:343,352); -logL from y'alpha and
+                                * diag(L) of the second factor (:362) */
 
 #define GPBO_ACQ_EI 0          /* BayesOpt_v4.ipynb:188-197 */
 #define GPBO_ACQ_UCB 1         /* GP/BayesOpt_v1.m:248-251 */
@@ -133,15 +135,19 @@ int gpbo_first_at_least(gpbo_ctx* ctx, double threshold, int64_t* index_out);
  * no hipMalloc / hipFree or any allocating routine: the partial results of its two reductions live in a 32 KiB
  * file-scope device array that every GPU the library runs on holds until the process ends.
  *   mu_dev, var_dev (m,) and acq_out_dev (m,) are DEVICE pointers owned by the caller; stream is a hipStream_t (NULL =
- *   the default stream); argmax_out / best_out / mu_max_out are host pointers (any may be NULL), valid on return (the
- *   call synchronises the stream).  incumbent_mode: GPBO_INCUMBENT_MAX_MU or GPBO_INCUMBENT_GIVEN (there is no model
- *   here, so no max(yTrain)).  Same arithmetic and tie rule as gpbo_acquire: results are bit-identical.
+ *   the default stream).  result_dev (DEVICE pointer to 4 doubles, may be NULL) receives {incumbent, max(mu), best
+ *   acquisition value, its index as the bit pattern of an int64}.  argmax_out / best_out / mu_max_out are host pointers
+ *   (any may be NULL): when at least one is given the call copies the results back and synchronises the stream; when all
+ *   three are NULL it only enqueues kernels -- no copy, no synchronisation -- which is the form to use on a capturing
+ *   stream (read the results from result_dev after the graph has run).  incumbent_mode: GPBO_INCUMBENT_MAX_MU or
+ *   GPBO_INCUMBENT_GIVEN (there is no model here, so no max(yTrain)).  Same arithmetic and tie rule as gpbo_acquire:
+ *   results are bit-identical.  The caller's current device is restored before returning.
  * Limits: 1 <= m <= 2^28 (268,435,456) candidates per call, larger sizes return GPBO_ERR_BAD_ARG and launch nothing;
  * device < 64.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two host threads,
  * two streams) race and must be serialised by the caller. */
 int gpbo_acquire_static(int32_t device, void* stream, const double* mu_dev, const double* var_dev, int64_t m,
                         int32_t acq, double kappa, int32_t incumbent_mode, double incumbent, double* acq_out_dev,
-                        int64_t* argmax_out, double* best_out, double* mu_max_out);
+                        double* result_dev, int64_t* argmax_out, double* best_out, double* mu_max_out);
 
 /* Copy count results starting at candidate offset to host; any pointer may be NULL.  acq: the values the last gpbo_acquire
  * stored; GPBO_ERR_BAD_ARG if the posterior has changed since (new candidates, model, appended point, uploaded posterior). */
@@ -235,6 +241,11 @@ int gpbo_set_timing(gpbo_ctx* ctx, int32_t enabled);
 
 /* Scalars of the current model: theta1 (BayesOpt_v4.ipynb:144), -logL (:164), max(yTrain), n.  Any may be NULL. */
 int gpbo_model_scalars(gpbo_ctx* ctx, double* theta1_out, double* nll_out, double* y_max_out, int64_t* n_out);
+
+/* Shapes the context currently holds: training points n, columns d, length m of the current posterior and the number of
+ * candidate rows resident in HBM.  Valid after a failed call as well (a fit that ends in GPBO_ERR_NOT_PD has already
+ * replaced n and d, and dropped resident candidates of another width): host wrappers re-read their bookkeeping from here. */
+int gpbo_shape(gpbo_ctx* ctx, int64_t* n_out, int32_t* d_out, int64_t* m_out, int64_t* candidate_rows_out);
 
 /* Conditioning diagnostic of the factored matrix (the one np.linalg.cholesky receives at BayesOpt_v4.ipynb:142, or
  * :147 for the v4 variant): (max diag L / min diag L)^2, a lower bound of its 2-norm condition number.  Needs the

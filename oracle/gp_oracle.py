@@ -71,9 +71,12 @@ def kernel_matrix(A, B, theta, kernel=RBF):
     return kernel_from_sqdist(scaled_sqdist(A, B, theta), kernel)
 
 
-def jitter(n, sigmaY):
-    """eps of BayesOpt_v4.ipynb:138-141 (scalar on the diagonal)."""
-    return 1e-15 * n if sigmaY == 0 else sigmaY ** 2
+def jitter(n, sigmaY, variant=0):
+    """eps of BayesOpt_v4.ipynb:138-141 (scalar on the diagonal).  The MATLAB two-factor form (variant 3) uses
+    eps*length(K) with MATLAB's eps = 2^-52 (GP/BayesOpt_v3.m:343,352)."""
+    if sigmaY == 0:
+        return (2.220446049250313e-16 if variant == 3 else 1e-15) * n
+    return sigmaY ** 2
 
 
 # --------------------------------------------------------------------------- fit
@@ -86,7 +89,7 @@ def fit(xTrain, yTrain, theta, sigmaY, kernel=RBF, variant=VARIANT_V4):
     theta = np.asarray(theta, dtype=np.float64).reshape(-1)
     n = X.shape[0]
     K0 = kernel_matrix(X, X, theta, kernel)
-    eps = jitter(n, sigmaY)
+    eps = jitter(n, sigmaY, variant)
     Keps = K0 + eps * np.eye(n)
     L1 = np.linalg.cholesky(Keps)                                 # :142
     alpha1 = solve_triangular(L1, y, lower=True)
@@ -104,7 +107,10 @@ def fit(xTrain, yTrain, theta, sigmaY, kernel=RBF, variant=VARIANT_V4):
         L2 = np.linalg.cholesky(theta1 * K0 + eps * np.eye(n))   # GP/BayesOpt_v3.m:350-351
         a2 = solve_triangular(L2, y, lower=True)
         st['L2'] = L2
-        st['alpha'] = solve_triangular(L2, a2, lower=True, trans='T')   # GP/BayesOpt_v3.m:352: alpha = L'\(L\y) with the second L
+        st['alpha'] = solve_triangular(L2, a2, lower=True, trans='T')   # GP/BayesOpt_v3.m:357: alpha = L'\(L\y) with the second L
+        # :362: logL from y'alpha and diag(L) of the second factor
+        st['nll'] = n / 2 * (math.log(2 * math.pi) + 1) + n / 2 * math.log(float(y @ st['alpha']) / n) \
+            + float(np.sum(np.log(np.diag(L2))))
     else:
         st['L2'] = None
         st['alpha'] = alpha1

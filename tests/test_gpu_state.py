@@ -269,3 +269,86 @@ def test_stored_acquisition_values_go_with_their_posterior(gp0):
     with pytest.raises(ValueError):
         gp0.first_at_least(0.0)
     gp0.reserve_appends(0)
+
+
+def test_tile_order_of_the_candidate_sweep_and_small_kernel_width_change_no_bit(tmp_path):
+    """GPBO_TRMM_COLGROUP only reorders the tiles of the variance product, and GPBO_SMALL_WIDE_MIN only picks the workgroup
+    width of the one-workgroup likelihood kernel: every number is produced by the same arithmetic in the same order, so the
+    posterior and the likelihoods must be bit-identical whatever they are set to."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from bayesian_optimization_amd import GP, synth
+n, d = 900, 3
+X = synth.uniform(51, n * d).reshape(n, d)
+y = np.sin(3 * X.sum(1)) + 0.1 * synth.normal(52, n)
+Xs = synth.uniform(53, 5000 * d).reshape(5000, d)
+gp = GP(0)
+gp.fit(X, y, np.array([0.4, 0.5, 0.6]), 0.05)
+mu, var, ei, idx, _, _ = gp.predict_ei(Xs, 0.01)
+nll, g, st = gp.lml_batch(X[:90], y[:90], np.array([[0.4, 0.5, 0.6], [0.3, 0.3, 0.3]]), [0.05, 0.1], grad=True)
+np.savez(sys.argv[1], mu=mu, var=var, ei=ei, idx=idx, lml=nll, g=g)
+'''
+    outs = []
+    for k, env_add in enumerate(({}, {'GPBO_TRMM_COLGROUP': '3'}, {'GPBO_TRMM_COLGROUP': '1', 'GPBO_SMALL_WIDE_MIN': '128'},
+                                 {'GPBO_SMALL_WIDE_MIN': '0'})):
+        path = str(tmp_path / ('order_%d.npz' % k))
+        proc = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, **env_add), cwd=ROOT, capture_output=True,
+                              text=True, timeout=150)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        outs.append(np.load(path))
+    for o2 in outs[1:]:
+        for key in ('mu', 'var', 'ei', 'idx', 'lml', 'g'):
+            assert np.array_equal(o2[key], outs[0][key]), key
+
+
+def test_nan_follows_numpy(gp0):
+    """np.max(Mu) is NaN as soon as one mean is NaN (BayesOpt_v4.ipynb:193), and np.argmax(ei) returns the first NaN (:647):
+    a poisoned posterior must surface, not be masked by the largest finite value."""
+    m = 5000
+    mu = np.sin(np.arange(m) * 0.01)
+    var = np.full(m, 0.04)
+    gp0.set_posterior(mu, var)
+    idx, best = gp0.acquire(bo.ACQ_UCB, 1.0)
+    u = mu + 1.0 * np.sqrt(var)
+    assert idx == int(np.argmax(u)) and best == u[idx]
+    mu2 = mu.copy()
+    mu2[[4321, 777, 2500]] = np.nan
+    gp0.set_posterior(mu2, var)
+    idx, best = gp0.acquire(bo.ACQ_UCB, 1.0)
+    assert idx == 777 and np.isnan(best) and idx == int(np.argmax(mu2 + np.sqrt(var)))
+    # EI with the notebook's incumbent max(Mu) = NaN: every value is NaN, the first index wins, as in the reference
+    idx, best = gp0.acquire(bo.ACQ_EI, 0.01, bo.INCUMBENT_MAX_MU)
+    ei = gp0.read(mu=False, var=False, acq=True)
+    ei_o = o.expected_improvement(mu2, var, 0.01)
+    assert np.all(np.isnan(ei)) and np.all(np.isnan(ei_o)) and idx == int(np.argmax(ei_o)) == 0 and np.isnan(best)
+    # a NaN variance only: max(mu) stays finite, the first NaN acquisition value is picked
+    var2 = var.copy()
+    var2[3000] = np.nan
+    gp0.set_posterior(mu, var2)
+    idx, best = gp0.acquire(bo.ACQ_EI, 0.01, bo.INCUMBENT_MAX_MU)
+    assert idx == 3000 and np.isnan(best)
+
+
+def test_failed_fit_leaves_wrapper_and_library_in_step():
+    """gpbo_fit replaces n, d and drops candidates of another width before the factorisation can fail; the wrapper must
+    hold the same shapes afterwards (it validates set_candidates / read against them)."""
+    g = bo.GP(0)
+    X, y = _data(50, 2, 5)
+    g.fit(X, y, np.array([0.3, 0.4]), 0.05)
+    g.set_candidates(o.splitmix64_uniform(3, 200).reshape(100, 2))
+    g.posterior()
+    X3 = np.vstack([o.splitmix64_uniform(4, 90).reshape(30, 3)] * 2)      # duplicated rows, no noise: not positive definite
+    with pytest.raises(np.linalg.LinAlgError):
+        g.fit(X3, np.ones(60), np.array([0.5, 0.5, 0.5]), 0.0)
+    assert (g.n, g.d, g.m, g._xs_rows) == (60, 3, 0, 0)
+    with pytest.raises(ValueError):
+        g.set_candidates(o.splitmix64_uniform(3, 200).reshape(100, 2))      # two columns: the library now expects three
+    with pytest.raises(ValueError):
+        g.read()
+    g.fit(X, y, np.array([0.3, 0.4]), 0.05)
+    g.set_candidates(o.splitmix64_uniform(3, 200).reshape(100, 2))
+    assert np.isfinite(g.posterior())
+    g.close()
