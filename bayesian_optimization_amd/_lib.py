@@ -81,6 +81,32 @@ SIGNATURES = {
     'gpbo_state_describe': (C.c_int, [C.c_void_p, C.POINTER(StateDesc)]),
     'gpbo_state_alloc': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     'gpbo_state_commit': (C.c_int, [C.c_void_p, C.c_double]),
+    'gpbo_device_count': (C.c_int, []),
+    'gpbo_multi_create': (C.c_int, [_i32p, C.c_int32, C.POINTER(C.c_void_p)]),
+    'gpbo_multi_destroy': (None, [C.c_void_p]),
+    'gpbo_multi_last_error': (C.c_char_p, [C.c_void_p]),
+    'gpbo_multi_last_info': (C.c_int64, [C.c_void_p]),
+    'gpbo_multi_size': (C.c_int32, [C.c_void_p]),
+    'gpbo_multi_context': (C.c_void_p, [C.c_void_p, C.c_int32]),
+    'gpbo_multi_block': (C.c_int, [C.c_void_p, C.c_int32, _i64p, _i64p]),
+    'gpbo_multi_shape': (C.c_int, [C.c_void_p, _i64p, _i32p, _i64p, _i64p]),
+    'gpbo_multi_reserve_appends': (C.c_int, [C.c_void_p, C.c_int64]),
+    'gpbo_multi_set_chunk': (C.c_int, [C.c_void_p, C.c_int64]),
+    'gpbo_multi_set_timing': (C.c_int, [C.c_void_p, C.c_int32]),
+    'gpbo_multi_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, C.c_double, C.c_int32, C.c_int32, _dp, _dp]),
+    'gpbo_multi_kriging_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, C.c_double, C.c_int32, _dp, _i32p, _dp]),
+    'gpbo_multi_set_candidates': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    'gpbo_multi_set_candidates_uniform': (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64]),
+    'gpbo_multi_posterior': (C.c_int, [C.c_void_p, _dp]),
+    'gpbo_multi_acquire': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, _i64p, _dp]),
+    'gpbo_multi_first_at_least': (C.c_int, [C.c_void_p, C.c_double, _i64p]),
+    'gpbo_multi_read': (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int64, C.c_int64]),
+    'gpbo_multi_set_posterior': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
+    'gpbo_multi_predict_ei': (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_double, C.c_int32, C.c_double, _dp, _dp, _dp, _i64p, _dp, _dp]),
+    'gpbo_multi_append': (C.c_int, [C.c_void_p, _dp, C.c_double, _dp]),
+    'gpbo_multi_append_acquire': (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_int32, C.c_double, C.c_int32, C.c_double, _dp, _i64p, _dp]),
+    'gpbo_multi_lml_batch': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, _dp, _dp, _i32p]),
+    'gpbo_multi_last_distribute': (C.c_int, [C.c_void_p, _dp, _dp]),
     'gpbo_set_chunk': (C.c_int, [C.c_void_p, C.c_int64]),
     'gpbo_selftest_gemm': (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
 }

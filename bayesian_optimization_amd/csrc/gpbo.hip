@@ -301,8 +301,10 @@ int chol_first_deferred(int nb, int batch) {
 }
 
 // The one-workgroup likelihood and descent routines use 1024 threads above this many training points, 256 up to it.
+// The 256-thread form holds the covariance matrix as 2 x 2 register tiles, i.e. at most 32 points: larger settings are
+// clamped to 32.
 int small_wide_min() {
-    static const int v = getenv("GPBO_SMALL_WIDE_MIN") ? atoi(getenv("GPBO_SMALL_WIDE_MIN")) : 32;
+    static const int v = std::max(0, std::min(32, getenv("GPBO_SMALL_WIDE_MIN") ? atoi(getenv("GPBO_SMALL_WIDE_MIN")) : 32));
     return v;
 }
 
@@ -2152,3 +2154,5 @@ int gpbo_selftest_gemm(gpbo_ctx* ctx, int32_t n, double* err_out, double* rate_o
 }
 
 }  // extern "C"
+
+#include "multi.hpp"

@@ -25,13 +25,16 @@ def _f64(a, ndim=None):
 
 
 class GP:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _borrowed=None):
         self._lib = L.load()
-        h = C.c_void_p()
-        st = self._lib.gpbo_create(int(device), C.byref(h))
-        if st != L.OK or not h.value:
-            raise GpboError('gpbo_create(device=%d) failed with status %d (no usable GPU?)' % (device, st))
-        self._h = h
+        if _borrowed is not None:      # a context owned by a MultiGP handle: used, never destroyed, from here
+            self._h, self._owned = C.c_void_p(_borrowed), False
+        else:
+            h = C.c_void_p()
+            st = self._lib.gpbo_create(int(device), C.byref(h))
+            if st != L.OK or not h.value:
+                raise GpboError('gpbo_create(device=%d) failed with status %d (no usable GPU?)' % (device, st))
+            self._h, self._owned = h, True
         self.device = int(device)
         self.n = self.d = self.m = 0
         self._xs_rows = 0        # candidate rows resident on the device (m is the length of the current posterior)
@@ -40,7 +43,8 @@ class GP:
     # ------------------------------------------------------------------ plumbing
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
-            self._lib.gpbo_destroy(self._h)
+            if self._owned:
+                self._lib.gpbo_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -313,3 +317,271 @@ class GP:
         err, r = C.c_double(), C.c_double()
         self._check(self._lib.gpbo_selftest_gemm(self._h, int(n), C.byref(err), C.byref(r) if rate else None))
         return (err.value, r.value) if rate else err.value
+
+
+class MultiGP:
+    """Several GPUs (or several contexts on one GPU) behind the call surface of ``GP``, in one process: the candidate set is
+    split into contiguous blocks, context 0 fits and hands the model over device to device, every sweep runs on all blocks
+    side by side, and max(Mu) / the argmax are reduced inside the library (include/gpbo.h, gpbo_multi_*).  Results are
+    bit-identical to one ``GP`` sweeping the whole set.  ``devices``: one entry per context, e.g. [0, 1, 2, 3] or [0, 0]."""
+
+    def __init__(self, devices):
+        self._lib = L.load()
+        devs = [int(v) for v in devices]
+        if not devs:
+            raise ValueError('MultiGP needs at least one device')
+        arr = (C.c_int32 * len(devs))(*devs)
+        h = C.c_void_p()
+        st = self._lib.gpbo_multi_create(arr, len(devs), C.byref(h))
+        if st != L.OK or not h.value:
+            raise GpboError('gpbo_multi_create(devices=%r) failed with status %d (no usable GPU?)' % (devs, st))
+        self._h = h
+        self.devices = devs
+        self.device = devs[0]
+        self.contexts = [GP(dv, _borrowed=self._lib.gpbo_multi_context(h, i)) for i, dv in enumerate(devs)]
+        self.n = self.d = self.m = 0
+        self._xs_rows = 0
+        self.theta1 = self.nll = float('nan')
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            for g in self.contexts:
+                g.close()
+            self._lib.gpbo_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st == L.OK:
+            return
+        msg = self._lib.gpbo_multi_last_error(self._h)
+        msg = msg.decode() if msg else ''
+        if st == L.ERR_NOT_PD:
+            raise np.linalg.LinAlgError(msg or 'Matrix is not positive definite')
+        if st == L.ERR_BAD_ARG:
+            raise ValueError(msg)
+        raise GpboError('HIP error: ' + msg)
+
+    def _sync_shape(self):
+        n, d, m, rows = C.c_int64(), C.c_int32(), C.c_int64(), C.c_int64()
+        self._lib.gpbo_multi_shape(self._h, C.byref(n), C.byref(d), C.byref(m), C.byref(rows))
+        self.n, self.d, self.m, self._xs_rows = int(n.value), int(d.value), int(m.value), int(rows.value)
+        for g in self.contexts:
+            g._sync_shape()
+
+    def blocks(self):
+        """[(lo, hi)] rows of the current posterior per context."""
+        out = []
+        for i in range(len(self.contexts)):
+            lo, hi = C.c_int64(), C.c_int64()
+            self._check(self._lib.gpbo_multi_block(self._h, i, C.byref(lo), C.byref(hi)))
+            out.append((int(lo.value), int(hi.value)))
+        return out
+
+    def timings(self):
+        """Per-context timing dictionaries (context 0 first)."""
+        return [g.timings() for g in self.contexts]
+
+    def set_timing(self, enabled: bool):
+        self._check(self._lib.gpbo_multi_set_timing(self._h, 1 if enabled else 0))
+
+    def set_chunk(self, chunk: int):
+        self._check(self._lib.gpbo_multi_set_chunk(self._h, int(chunk)))
+
+    def last_distribute(self):
+        """(milliseconds, bytes) of the model hand-over of the last fit."""
+        ms, by = C.c_double(), C.c_double()
+        self._check(self._lib.gpbo_multi_last_distribute(self._h, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    # ------------------------------------------------------------------ model
+    def fit(self, xTrain, yTrain, theta, sigmaY, kernel=L.KERNEL_RBF, variant=L.VARIANT_V4):
+        X = _f64(xTrain, 2)
+        y = _f64(np.asarray(yTrain).reshape(-1), 1)
+        th = _f64(np.asarray(theta).reshape(-1), 1)
+        if y.shape[0] != X.shape[0]:
+            raise ValueError('xTrain has %d rows, yTrain %d' % (X.shape[0], y.shape[0]))
+        if th.shape[0] != X.shape[1]:
+            raise ValueError('theta has %d entries, xTrain %d columns' % (th.shape[0], X.shape[1]))
+        t1, nll = C.c_double(), C.c_double()
+        try:
+            self._check(self._lib.gpbo_multi_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th),
+                                                 float(sigmaY), int(kernel), int(variant), C.byref(t1), C.byref(nll)))
+        finally:
+            self._sync_shape()
+        self.theta1, self.nll = t1.value, nll.value
+        return self
+
+    def kriging_fit(self, xT, yT, theta, deg):
+        X = _f64(xT, 2)
+        y = _f64(np.asarray(yT).reshape(-1), 1)
+        if y.shape[0] != X.shape[0]:
+            raise ValueError('xT has %d rows, yT %d' % (X.shape[0], y.shape[0]))
+        beta = np.zeros(10)
+        nb, cov = C.c_int32(), C.c_double()
+        try:
+            self._check(self._lib.gpbo_multi_kriging_fit(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1],
+                                                         float(np.squeeze(theta)), int(deg), L.dptr(beta), C.byref(nb), C.byref(cov)))
+        finally:
+            self._sync_shape()
+        self.theta1, self.nll = cov.value, float('nan')
+        return beta[:nb.value].copy(), cov.value
+
+    def set_candidates(self, xTest):
+        Xs = _f64(xTest, 2)
+        if Xs.shape[1] != self.d:
+            raise ValueError('xTest has %d columns, the model %d' % (Xs.shape[1], self.d))
+        try:
+            self._check(self._lib.gpbo_multi_set_candidates(self._h, Xs.ctypes.data_as(C.c_void_p), Xs.shape[0], 0))
+        finally:
+            self._sync_shape()
+        return self
+
+    def set_candidates_uniform(self, seed: int, row_offset: int, m: int):
+        try:
+            self._check(self._lib.gpbo_multi_set_candidates_uniform(self._h, int(seed), int(row_offset), int(m)))
+        finally:
+            self._sync_shape()
+        return self
+
+    def posterior(self):
+        mm = C.c_double()
+        try:
+            self._check(self._lib.gpbo_multi_posterior(self._h, C.byref(mm)))
+        finally:
+            self._sync_shape()
+        return mm.value
+
+    def acquire(self, acq=L.ACQ_EI, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0, tie_rtol=0.0):
+        idx, best = C.c_int64(), C.c_double()
+        self._check(self._lib.gpbo_multi_acquire(self._h, int(acq), float(kappa), int(incumbent_mode), float(incumbent),
+                                                 C.byref(idx), C.byref(best)))
+        if tie_rtol > 0.0 and np.isfinite(best.value):
+            first = self.first_at_least(best.value - float(tie_rtol) * abs(best.value))
+            if first >= 0:
+                return first, best.value
+        return int(idx.value), best.value
+
+    def first_at_least(self, threshold):
+        idx = C.c_int64()
+        self._check(self._lib.gpbo_multi_first_at_least(self._h, float(threshold), C.byref(idx)))
+        return int(idx.value)
+
+    def read(self, mu=True, var=True, acq=False, offset=0, count=None):
+        count = self.m - offset if count is None else count
+        bufs = [np.empty(count) if want else None for want in (mu, var, acq)]
+        self._check(self._lib.gpbo_multi_read(self._h, *[L.dptr(b) if b is not None else None for b in bufs], int(offset), int(count)))
+        out = [b for b in bufs if b is not None]
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def predict_ei(self, xTest, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0):
+        Xs = _f64(xTest, 2)
+        if Xs.shape[1] != self.d:
+            raise ValueError('xTest has %d columns, the model %d' % (Xs.shape[1], self.d))
+        m = Xs.shape[0]
+        mu, var, ei = np.empty(m), np.empty(m), np.empty(m)
+        idx, eim, mum = C.c_int64(), C.c_double(), C.c_double()
+        try:
+            self._check(self._lib.gpbo_multi_predict_ei(self._h, L.dptr(Xs), m, float(kappa), int(incumbent_mode), float(incumbent),
+                                                        L.dptr(mu), L.dptr(var), L.dptr(ei), C.byref(idx), C.byref(eim), C.byref(mum)))
+        finally:
+            self._sync_shape()
+        return mu, var, ei, int(idx.value), eim.value, mum.value
+
+    def set_posterior(self, mu, var):
+        mu = _f64(np.asarray(mu).reshape(-1), 1)
+        var = _f64(np.asarray(var).reshape(-1), 1)
+        if mu.shape != var.shape:
+            raise ValueError('mu and var must have the same length')
+        try:
+            self._check(self._lib.gpbo_multi_set_posterior(self._h, L.dptr(mu), L.dptr(var), mu.shape[0]))
+        finally:
+            self._sync_shape()
+
+    def reserve_appends(self, max_appends: int):
+        self._check(self._lib.gpbo_multi_reserve_appends(self._h, int(max_appends)))
+
+    def append(self, x_new, y_new):
+        x = _f64(np.asarray(x_new).reshape(-1), 1)
+        if x.shape[0] != self.d:
+            raise ValueError('x_new has %d entries, the model %d columns' % (x.shape[0], self.d))
+        mm = C.c_double()
+        try:
+            self._check(self._lib.gpbo_multi_append(self._h, L.dptr(x), float(y_new), C.byref(mm)))
+        finally:
+            self._sync_shape()
+        self._refresh_scalars()
+        return mm.value
+
+    def append_acquire(self, x_new, y_new, acq=L.ACQ_EI, kappa=0.01, incumbent_mode=L.INCUMBENT_MAX_MU, incumbent=0.0):
+        x = _f64(np.asarray(x_new).reshape(-1), 1)
+        if x.shape[0] != self.d:
+            raise ValueError('x_new has %d entries, the model %d columns' % (x.shape[0], self.d))
+        mm, idx, best = C.c_double(), C.c_int64(), C.c_double()
+        try:
+            self._check(self._lib.gpbo_multi_append_acquire(self._h, L.dptr(x), float(y_new), int(acq), float(kappa), int(incumbent_mode),
+                                                            float(incumbent), C.byref(mm), C.byref(idx), C.byref(best)))
+        finally:
+            self._sync_shape()
+        self._refresh_scalars()
+        return mm.value, int(idx.value), best.value
+
+    def _refresh_scalars(self):
+        g = self.contexts[0]
+        g._refresh_scalars()
+        self.theta1, self.nll, self.y_max, self.n = g.theta1, g.nll, g.y_max, g.n
+
+    def lml_batch(self, xTrain, yTrain, thetas, sigmas, kernel=L.KERNEL_RBF, grad=False):
+        X = _f64(xTrain, 2)
+        y = _f64(np.asarray(yTrain).reshape(-1), 1)
+        th = _f64(thetas, 2)
+        sg = _f64(np.asarray(sigmas).reshape(-1), 1)
+        B = th.shape[0]
+        if th.shape[1] != X.shape[1] or sg.shape[0] != B:
+            raise ValueError('thetas must be (B,d) and sigmas (B,)')
+        nll = np.empty(B)
+        g = np.empty((B, X.shape[1])) if grad else None
+        stat = np.zeros(B, dtype=np.int32)
+        self._check(self._lib.gpbo_multi_lml_batch(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th), L.dptr(sg),
+                                                   B, int(kernel), L.dptr(nll), L.dptr(g) if grad else None,
+                                                   stat.ctypes.data_as(C.POINTER(C.c_int32))))
+        return (nll, g, stat) if grad else (nll, stat)
+
+    # what only the fitting context can answer, or what needs no split
+    def factor(self, want_L=True, want_alpha=True):
+        if want_L:
+            self.factor_downloads = getattr(self, 'factor_downloads', 0) + 1
+        return self.contexts[0].factor(want_L, want_alpha)
+
+    def cond_estimate(self):
+        return self.contexts[0].cond_estimate()
+
+    def kernel_matrix(self, U, V, theta, kernel=L.KERNEL_RBF):
+        return self.contexts[0].kernel_matrix(U, V, theta, kernel)
+
+    def kernel_from_distances(self, Daa, theta, kernel=L.KERNEL_RBF):
+        return self.contexts[0].kernel_from_distances(Daa, theta, kernel)
+
+    def descent_small(self, *args, **kwargs):
+        return self.contexts[0].descent_small(*args, **kwargs)
+
+
+def device_count():
+    """GPUs visible to the library (0 when there is none)."""
+    return int(L.load().gpbo_device_count())
+
+
+def make_gp(devices=None):
+    """A ``GP`` on one device or a ``MultiGP`` over several.  devices=None: every visible GPU, or the list in the environment
+    variable GPBO_DEVICES (comma-separated; an id may repeat, e.g. "0,0" = two contexts on GPU 0)."""
+    import os
+    if devices is None:
+        env = os.environ.get('GPBO_DEVICES')
+        devices = [int(v) for v in env.split(',')] if env else list(range(max(1, device_count())))
+    devices = [int(v) for v in np.atleast_1d(devices)]
+    return GP(devices[0]) if len(devices) == 1 else MultiGP(devices)

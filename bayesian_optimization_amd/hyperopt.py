@@ -17,18 +17,20 @@ import os
 
 import numpy as np
 
-from .gp import GP
+from .gp import GP, make_gp
 
 _ctx = {}
 
 
-def _lml_gp(device=0):
+def _lml_gp(device=None):
+    """device=None: every visible GPU (the starts of a multi-start fit are the batch axis of the likelihood sweep and split
+    over the devices); an int: that device only."""
     if device not in _ctx:
-        _ctx[device] = GP(device)
+        _ctx[device] = make_gp() if device is None else GP(device)
     return _ctx[device]
 
 
-def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, steprule, max_its, W0, device=0, kernel=0):
+def conj_gradient_descent_batched(xTrain, yTrain, sigmaY, alpha, beta, norm, steprule, max_its, W0, device=None, kernel=0):
     """All rows of W0 (nruns, d) advance in lockstep.  Returns (weight_history, cost_history, exitflag):
     weight_history[r] is the list of iterates of start r, cost_history[r] the -logL at each of them."""
     gp = _lml_gp(device)

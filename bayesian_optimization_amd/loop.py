@@ -11,16 +11,17 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib as L
-from .gp import GP
+from .gp import make_gp
 from .hyperopt import hypopt_wrap
 
 
 def bayes_opt(x, y, xT, yT, sigmaY=0.0, kappa=0.01, ei_tol=1e-9, nruns=10, max_its=1e3, alpha=0.01, beta=1,
               normrule='component', steprule='normal', max_iter=None, kernel=L.KERNEL_RBF, keep_history=False,
-              starts=None, callback=None, device=0, gp=None):
+              starts=None, callback=None, device=None, gp=None, devices=None):
     """x (m, d): the candidate set; y: its objective values (m,) / (m, 1), or a callable evaluated at the picked row.
     xT (n0, d), yT (n0, 1): the initial training set.  starts: optional callable (iteration, d) -> (nruns, d) starting points of
     the descent (default np.random.rand per start, as the reference).  callback(k, state) sees every iteration's record.
+    devices: GPU ids to split the candidate set over (default: every visible GPU; ``device``: a single one).
     Returns a dict: xT, yT (grown), theta_hist, jj_hist, ei_max_hist, exitflag (1: EI fell below ei_tol, 0: max_iter reached)
     and, with keep_history, Mu_hist / Var_hist / EI_hist."""
     x = np.ascontiguousarray(x, dtype=np.float64)
@@ -34,7 +35,7 @@ def bayes_opt(x, y, xT, yT, sigmaY=0.0, kappa=0.01, ei_tol=1e-9, nruns=10, max_i
     y_tab = None if callable(y) else np.asarray(y, dtype=np.float64).reshape(-1)
     if y_tab is not None and y_tab.shape[0] != x.shape[0]:
         raise ValueError('y has %d entries, x %d rows' % (y_tab.shape[0], x.shape[0]))
-    gp = gp or GP(device)
+    gp = gp or make_gp(devices if devices is not None else ([device] if device is not None else None))
     out = {'theta_hist': [], 'jj_hist': [], 'ei_max_hist': [], 'exitflag': 0}
     if keep_history:
         out.update(Mu_hist=[], Var_hist=[], EI_hist=[])

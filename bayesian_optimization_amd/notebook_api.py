@@ -22,18 +22,27 @@ import weakref
 import numpy as np
 
 from . import _lib as L
-from .gp import GP
+from .gp import GP, make_gp
 from .hyperopt import hypopt, hypopt_wrap  # noqa: F401  (BayesOpt_v4.ipynb:167-186, batched over the starts)
 from .loop import bayes_opt  # noqa: F401  (the while loop of BayesOpt_v4.ipynb:618-664)
 
 _ctx = {}
 
 
-def _gp(kind='main', device=0):
-    key = (kind, device)
-    if key not in _ctx:
-        _ctx[key] = GP(device)
-    return _ctx[key]
+def _gp(kind='main'):
+    """The context behind the functions of this module, one per role.  The sweeping roles ('main': gprfcn /
+    expected_improvement, 'kriging', 'lml') span every visible GPU (or the list in GPBO_DEVICES) through a MultiGP: the
+    candidate set of a call is split over the devices inside the library; 'aux' (small matrices on request) stays on one."""
+    if kind not in _ctx:
+        _ctx[kind] = GP(0) if kind == 'aux' else make_gp()
+    return _ctx[kind]
+
+
+def release():
+    """Destroy the module's contexts (device memory, host threads).  The next call creates them again."""
+    for g in _ctx.values():
+        g.close()
+    _ctx.clear()
 
 
 # ----------------------------------------------------------------------------- lazy containers

@@ -261,6 +261,60 @@ int gpbo_state_describe(gpbo_ctx* ctx, gpbo_state_desc* out);
 int gpbo_state_alloc(gpbo_ctx* ctx, int64_t n, int64_t n_pad, int32_t d, int32_t kernel, int32_t variant, double sigmaY);
 int gpbo_state_commit(gpbo_ctx* ctx, double y_max);
 
+/* ---- Several GPUs behind one handle, in ONE process (the notebooks are one Jupyter process).  No counterpart in the
+ * reference, which runs on one CPU: the loop body that is split is BayesOpt_v4.ipynb:642-647.  A gpbo_multi owns one
+ * context per entry of `devices` (an entry may repeat: several contexts on one GPU) and one host thread per context.
+ * Candidates are split into contiguous blocks in context order (the first m % N blocks one row longer), so a global
+ * index is block offset + local index and the first-occurrence argmax (:647) survives the split.  gpbo_multi_fit fits on
+ * context 0 and hands W = L^-1, alpha, the scaled inputs and the scalar block to the other contexts device to device: W
+ * in N - 1 slices, slice s to context s + 1, then exchanged among the receivers, so that every link carries 2 / (N - 1)
+ * of W.  (After gpbo_multi_reserve_appends a single-factor fit is instead carried out on every context: the frozen-theta
+ * loop appends on all of them and never exchanges the model.)  gpbo_multi_posterior / _acquire run all blocks side by
+ * side; max(Mu) (the EI incumbent, :193) and the (value, lowest index) pair of the argmax are reduced on the host, with
+ * numpy's NaN rules.  Every result is bit-identical to one context sweeping the whole set.
+ * Status codes, argument meaning and ownership as for the single-context calls of the same name. */
+typedef struct gpbo_multi gpbo_multi;
+int gpbo_device_count(void);
+int gpbo_multi_create(const int32_t* devices, int32_t n_contexts, gpbo_multi** out);
+void gpbo_multi_destroy(gpbo_multi* mg);
+const char* gpbo_multi_last_error(gpbo_multi* mg);
+int64_t gpbo_multi_last_info(gpbo_multi* mg);
+int32_t gpbo_multi_size(gpbo_multi* mg);
+/* Context i (owned by the handle; 0 holds the factor): for gpbo_last_timings, gpbo_get_factor, gpbo_kernel_matrix ... */
+gpbo_ctx* gpbo_multi_context(gpbo_multi* mg, int32_t i);
+/* Rows [lo, hi) of the current posterior that context i holds. */
+int gpbo_multi_block(gpbo_multi* mg, int32_t i, int64_t* lo_out, int64_t* hi_out);
+int gpbo_multi_shape(gpbo_multi* mg, int64_t* n_out, int32_t* d_out, int64_t* m_out, int64_t* candidate_rows_out);
+int gpbo_multi_reserve_appends(gpbo_multi* mg, int64_t max_appends);
+int gpbo_multi_set_chunk(gpbo_multi* mg, int64_t chunk);
+int gpbo_multi_set_timing(gpbo_multi* mg, int32_t enabled);
+int gpbo_multi_fit(gpbo_multi* mg, const double* X, const double* y, int64_t n, int32_t d, const double* theta, double sigmaY,
+                   int32_t kernel, int32_t variant, double* theta1_out, double* nll_out);
+int gpbo_multi_kriging_fit(gpbo_multi* mg, const double* X, const double* y, int64_t n, int32_t d, double theta, int32_t deg,
+                           double* beta_out, int32_t* nbeta_out, double* cov_out);
+int gpbo_multi_set_candidates(gpbo_multi* mg, const double* Xs, int64_t m, int32_t on_device);
+/* Context i generates rows [row_offset + lo_i, row_offset + hi_i) of the synthetic set itself. */
+int gpbo_multi_set_candidates_uniform(gpbo_multi* mg, uint64_t seed, int64_t row_offset, int64_t m);
+int gpbo_multi_posterior(gpbo_multi* mg, double* mu_max_out);
+int gpbo_multi_acquire(gpbo_multi* mg, int32_t acq, double kappa, int32_t incumbent_mode, double incumbent, int64_t* argmax_out,
+                       double* best_out);
+int gpbo_multi_first_at_least(gpbo_multi* mg, double threshold, int64_t* index_out);
+int gpbo_multi_read(gpbo_multi* mg, double* mu, double* var, double* acq, int64_t offset, int64_t count);
+int gpbo_multi_set_posterior(gpbo_multi* mg, const double* mu, const double* var, int64_t m);
+int gpbo_multi_predict_ei(gpbo_multi* mg, const double* Xs, int64_t m, double kappa, int32_t incumbent_mode, double incumbent,
+                          double* mu_out, double* var_out, double* ei_out, int64_t* argmax_out, double* ei_max_out,
+                          double* mu_max_out);
+int gpbo_multi_append(gpbo_multi* mg, const double* x_new, double y_new, double* mu_max_out);
+/* With more than one context the incumbent max(Mu) needs the host reduction between the two halves: two synchronisations
+ * per iteration instead of the one of gpbo_append_acquire. */
+int gpbo_multi_append_acquire(gpbo_multi* mg, const double* x_new, double y_new, int32_t acq, double kappa, int32_t incumbent_mode,
+                              double incumbent, double* mu_max_out, int64_t* argmax_out, double* best_out);
+/* The B settings are independent: context i evaluates a contiguous block of them, nothing is exchanged. */
+int gpbo_multi_lml_batch(gpbo_multi* mg, const double* X, const double* y, int64_t n, int32_t d, const double* thetas,
+                         const double* sigmas, int32_t B, int32_t kernel, double* nll_out, double* grad_out, int32_t* status_out);
+/* Wall time (ms) and bytes moved by the model hand-over of the last gpbo_multi_fit / gpbo_multi_kriging_fit. */
+int gpbo_multi_last_distribute(gpbo_multi* mg, double* ms_out, double* bytes_out);
+
 /* Tuning knob: candidates per posterior chunk (multiple of 128; 0 = default). */
 int gpbo_set_chunk(gpbo_ctx* ctx, int64_t chunk);
 

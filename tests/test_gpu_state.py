@@ -274,7 +274,8 @@ def test_stored_acquisition_values_go_with_their_posterior(gp0):
 def test_tile_order_of_the_candidate_sweep_and_small_kernel_width_change_no_bit(tmp_path):
     """GPBO_TRMM_COLGROUP only reorders the tiles of the variance product, and GPBO_SMALL_WIDE_MIN only picks the workgroup
     width of the one-workgroup likelihood kernel: every number is produced by the same arithmetic in the same order, so the
-    posterior and the likelihoods must be bit-identical whatever they are set to."""
+    posterior must be bit-identical whatever the tile order is; the two workgroup widths of the small kernel tile the matrix differently
+    and must agree at least to round-off (30 points: the default takes the 256-thread form, the other settings the 1024-thread form)."""
     import subprocess
     import sys
     code = r'''
@@ -288,11 +289,11 @@ Xs = synth.uniform(53, 5000 * d).reshape(5000, d)
 gp = GP(0)
 gp.fit(X, y, np.array([0.4, 0.5, 0.6]), 0.05)
 mu, var, ei, idx, _, _ = gp.predict_ei(Xs, 0.01)
-nll, g, st = gp.lml_batch(X[:90], y[:90], np.array([[0.4, 0.5, 0.6], [0.3, 0.3, 0.3]]), [0.05, 0.1], grad=True)
+nll, g, st = gp.lml_batch(X[:30], y[:30], np.array([[0.4, 0.5, 0.6], [0.3, 0.3, 0.3]]), [0.05, 0.1], grad=True)
 np.savez(sys.argv[1], mu=mu, var=var, ei=ei, idx=idx, lml=nll, g=g)
 '''
     outs = []
-    for k, env_add in enumerate(({}, {'GPBO_TRMM_COLGROUP': '3'}, {'GPBO_TRMM_COLGROUP': '1', 'GPBO_SMALL_WIDE_MIN': '128'},
+    for k, env_add in enumerate(({}, {'GPBO_TRMM_COLGROUP': '3'}, {'GPBO_TRMM_COLGROUP': '1', 'GPBO_SMALL_WIDE_MIN': '16'},
                                  {'GPBO_SMALL_WIDE_MIN': '0'})):
         path = str(tmp_path / ('order_%d.npz' % k))
         proc = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, **env_add), cwd=ROOT, capture_output=True,
@@ -300,8 +301,9 @@ np.savez(sys.argv[1], mu=mu, var=var, ei=ei, idx=idx, lml=nll, g=g)
         assert proc.returncode == 0, proc.stderr[-2000:]
         outs.append(np.load(path))
     for o2 in outs[1:]:
-        for key in ('mu', 'var', 'ei', 'idx', 'lml', 'g'):
+        for key in ('mu', 'var', 'ei', 'idx'):
             assert np.array_equal(o2[key], outs[0][key]), key
+        assert np.all(np.isfinite(o2['lml'])) and relmax(o2['lml'], outs[0]['lml']) <= 1e-12 and relmax(o2['g'], outs[0]['g']) <= 1e-10
 
 
 def test_nan_follows_numpy(gp0):

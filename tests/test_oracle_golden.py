@@ -194,7 +194,7 @@ def test_batched_descent_rule_walks_the_reference_paths(monkeypatch, tag, norm, 
     against the batched restatement of its update rules in bayesian_optimization_amd/hyperopt.py, the likelihood sweep
     replaced by the CPU restatement: host logic only."""
     from bayesian_optimization_amd import hyperopt
-    monkeypatch.setitem(hyperopt._ctx, 0, _OracleLml())
+    monkeypatch.setitem(hyperopt._ctx, None, _OracleLml())
     check_descent_case(hyperopt.hypopt, golden('g9_descent_paths'), tag, norm, step, 1e-9)
 
 
