@@ -342,7 +342,8 @@ def test_failed_fit_leaves_wrapper_and_library_in_step():
     g.fit(X, y, np.array([0.3, 0.4]), 0.05)
     g.set_candidates(o.splitmix64_uniform(3, 200).reshape(100, 2))
     g.posterior()
-    X3 = np.vstack([o.splitmix64_uniform(4, 90).reshape(30, 3)] * 2)      # duplicated rows, no noise: not positive definite
+    X3 = o.splitmix64_uniform(4, 180).reshape(60, 3)
+    X3[7, 1] = np.nan                                     # a NaN pivot is reported as not positive definite (LAPACK dpotrf rule)
     with pytest.raises(np.linalg.LinAlgError):
         g.fit(X3, np.ones(60), np.array([0.5, 0.5, 0.5]), 0.0)
     assert (g.n, g.d, g.m, g._xs_rows) == (60, 3, 0, 0)
