@@ -6,7 +6,9 @@ first-occurrence argmax survives sharding).  The data path has exactly two excha
   1. all-reduce(MAX) of one double: the EI incumbent max(Mu) (BayesOpt/BayesOpt_v4.ipynb:193);
   2. all-gather of (acquisition max, global index) per rank, reduced to max value / lowest index.
 The fitted model (inverse factor W, alpha, scaled inputs, scalars) is computed on rank `src`
-only and broadcast once per fit.
+only and handed over once per fit: the small buffers by broadcast, W by scatter + all-gather over every link.
+(One process driving several GPUs takes the route of gp.MultiGP / gpbo_multi_* instead; this module is the
+one-process-per-GPU form that torchrun launches.)
 """
 from __future__ import annotations
 
@@ -113,9 +115,57 @@ def model_tensors(gp):
     return out, sd
 
 
+def slice_bounds(length: int, parts: int, s: int):
+    """Element range [lo, hi) of slice s when `length` elements are cut into `parts` contiguous slices."""
+    return length * s // parts, length * (s + 1) // parts
+
+
+def scatter_allgather(t, src: int = 0):
+    """Give every rank the contents rank `src` holds in the 1-D tensor t (same length everywhere), using every link once
+    instead of one root fan-out: the tensor is cut into world - 1 slices; stage 1: src sends slice s to the s-th other rank
+    (each of the root's links carries one slice); stage 2: the receivers exchange their slices among themselves, pairwise
+    (each peer-to-peer link carries one slice each way).  Per link 2 / (world - 1) of the tensor moves, where a broadcast
+    from one root pushes all of it through every link of the root, or hops it around a ring.  xGMI is point to point: on an
+    8-GPU node the 8.6 GB inverse factor of a 32768-point model is 1.2 GB per link and stage."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    receivers = [r for r in range(world) if r != src]
+    P = len(receivers)
+    n = t.numel()
+    ops = []
+    if rank == src:
+        for s, r in enumerate(receivers):
+            lo, hi = slice_bounds(n, P, s)
+            if hi > lo:
+                ops.append(dist.P2POp(dist.isend, t[lo:hi], r))
+    else:
+        lo, hi = slice_bounds(n, P, receivers.index(rank))
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, t[lo:hi], src))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank == src or P == 1:
+        return
+    mine = receivers.index(rank)
+    mlo, mhi = slice_bounds(n, P, mine)
+    ops = []
+    for s, q in enumerate(receivers):
+        if q == rank:
+            continue
+        lo, hi = slice_bounds(n, P, s)
+        if mhi > mlo:
+            ops.append(dist.P2POp(dist.isend, t[mlo:mhi], q))
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, t[lo:hi], q))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
 def broadcast_model(gp, src: int = 0):
-    """After gp.fit() on rank `src`: give every other rank the same model.  Shapes travel first
-    (one small tensor), then the four device buffers are broadcast in place over RCCL."""
+    """After gp.fit() on rank `src`: give every other rank the same model.  Shapes travel first (one small tensor), then
+    the device buffers are filled in place: alpha, the scaled inputs and the scalar block by a plain broadcast (a few
+    hundred kilobytes), the inverse factor W by scatter_allgather."""
     if not _is_dist():
         return
     rank = dist.get_rank()
@@ -136,17 +186,23 @@ def broadcast_model(gp, src: int = 0):
     if (sd_local.W_bytes, sd_local.alpha_bytes) != want:
         raise RuntimeError('broadcast_model: rank %d holds buffers of %r bytes, the sender\'s are %r' %
                            (rank, (sd_local.W_bytes, sd_local.alpha_bytes), want))
+    W, small = tensors[0], tensors[1:]
     if dist.get_backend() == 'nccl':
         torch.cuda.synchronize(gp.device)
-        for t in tensors:
+        for t in small:
             dist.broadcast(t, src)
+        scatter_allgather(W, src)
         torch.cuda.synchronize(gp.device)
     else:                                            # gloo: stage through host memory
-        for t in tensors:
+        for t in small:
             h = t.cpu()
             dist.broadcast(h, src)
             if rank != src:
                 t.copy_(h)
+        h = W.cpu()
+        scatter_allgather(h, src)
+        if rank != src:
+            W.copy_(h)
         torch.cuda.synchronize(gp.device)
     if rank != src:
         gp.state_commit(y_max)

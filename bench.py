@@ -13,10 +13,14 @@ A step = one full pass over this rank's resident candidate block: K(X*,X) tiles,
 The model is fitted once (rank 0) and broadcast before the timed region; candidates are resident in HBM.
 value = candidates processed by all ranks / max-over-ranks time.  Rank 0 prints one JSON line.
 
-The default line measures BASELINE.json's 4096-point configuration (cfg2) and carries three more blocks: "cfg3", the
-32768-point Matern-5/2 model of the 64 M-candidate configuration on a bounded slice of its candidates; "cfg4", 200 EI
-iterations with incremental updates on the 64^4 candidate lattice; "cfg5", 32 likelihood settings per GPU at n = 16384
-(--no-cfg3 / --no-cfg45 leave them out).
+The default line measures BASELINE.json's 4096-point configuration (cfg2) and carries more blocks: "cfg3", the
+32768-point Matern-5/2 model of the 64 M-candidate configuration on a bounded slice of its candidates per GPU; with more
+than one GPU "cfg3_strong", ONE fixed candidate set of that model split over the ranks, with the fit on rank 0 and the
+hand-over of the model inside its end-to-end figure; "cfg4", 200 EI iterations with incremental updates on the 64^4
+candidate lattice; "cfg5", 32 likelihood settings per GPU at n = 16384 (--no-cfg3 / --no-cfg45 leave them out).
+
+--single-process drives the N GPUs from ONE process through the library's multi-context handle (gpbo_multi_*, the route
+the notebooks take: no launcher, no torch.distributed) and prints the same line shape for the chosen configuration.
 """
 import argparse
 import json
@@ -377,6 +381,68 @@ def cfg5_block(a, gp, world, rank, backend, per, steps, warmup):
                      'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None}}
 
 
+def single_process(a):
+    """--single-process: one process, one multi-context handle over a.gpus GPUs (gpbo_multi_*).  A step = the whole
+    candidate set of the configuration, split into one block per GPU inside the library: posterior on every block side by
+    side, host-side max(Mu), acquisition on every block, host-side argmax."""
+    from bayesian_optimization_amd import MultiGP, synth
+    cfg = dict(synth.CONFIGS[a.config])
+    if a.n:
+        cfg['n'] = a.n
+    m_total = a.m if a.m else cfg['m']
+    if a.config == 'cfg3' and not a.m:
+        m_total = (1 << 18) * a.gpus          # a bounded slice per GPU (stated in config.workload)
+    devs = [int(v) for v in os.environ['GPBO_DEVICES'].split(',')] if os.environ.get('GPBO_DEVICES') else list(range(a.gpus))
+    gp = MultiGP(devs)
+    if a.chunk:
+        gp.set_chunk(a.chunk)
+    X, y, theta = synth.training_set(cfg)
+    t0 = time.perf_counter()
+    gp.fit(X, y, theta, cfg['sigmaY'], kernel=cfg['kernel'])
+    fit_s = time.perf_counter() - t0
+    dist_ms, dist_bytes = gp.last_distribute()
+    gp.set_candidates_uniform(cfg['seed_c'], 0, m_total)
+    for _ in range(a.warmup):
+        gp.posterior()
+        gp.acquire(0, cfg['kappa'])
+    t0 = time.perf_counter()
+    trmm_ms = [0.0] * len(devs)
+    launches = [0.0] * len(devs)
+    for _ in range(a.steps):
+        mu_max = gp.posterior()
+        gidx, gbest = gp.acquire(0, cfg['kappa'])
+        for i, tm in enumerate(gp.timings()):
+            trmm_ms[i] += tm['trmm_ms']
+            launches[i] += tm['trmm_launches']
+    dt = time.perf_counter() - t0
+    n = cfg['n']
+    blocks = gp.blocks()
+    per_ctx = [float(n) * n * (hi - lo) * a.steps / max(ms * 1e-3, 1e-12) / 1e12 for (lo, hi), ms in zip(blocks, trmm_ms)]
+    slow = int(np.argmin(per_ctx))
+    cand_per_launch = (blocks[slow][1] - blocks[slow][0]) * a.steps / max(launches[slow], 1)
+    out = {
+        'metric': 'gp_posterior_ei_candidates_per_sec', 'value': m_total * a.steps / dt, 'unit': 'candidates/s',
+        'n_gpus': len(devs), 'processes': 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '%s: n=%d train, d=%d, %s, %d candidates split over %d contexts (devices %s) in one process, '
+                               'sigmaY=%g, theta=%g, EI kappa=%g'
+                               % (a.config, n, cfg['d'], 'RBF' if cfg['kernel'] == 0 else 'Matern-5/2', m_total, len(devs),
+                                  ','.join(map(str, devs)), cfg['sigmaY'], cfg['theta'], cfg['kappa']),
+                   'candidates_total': m_total, 'n_train': n, 'd': cfg['d'],
+                   'parallelism': 'one process, one context + host thread per GPU; host-side max(mu) and argmax'},
+        'roofline': {'bound': 'mfma', 'kernel': 'k_trmm_sumsq', 'achieved': per_ctx[slow], 'peak': FP64_MFMA_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': per_ctx[slow] / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'context': slow, 'per_context_tflops': per_ctx, 'flops_per_launch': float(n) * n * cand_per_launch,
+                     'avg_launch_ms': trmm_ms[slow] / max(launches[slow], 1), 'launches': launches[slow]},
+        'end_to_end': {'fit_and_distribute_ms': fit_s * 1e3, 'distribute_ms': dist_ms, 'distribute_bytes': dist_bytes,
+                       'sweep_ms': dt / a.steps * 1e3,
+                       'candidates_per_sec_incl_fit_and_distribute': m_total / (fit_s + dt / a.steps)},
+        'argmax': {'index': int(gidx), 'ei': gbest, 'mu_max': mu_max},
+    }
+    print(json.dumps(out), flush=True)
+    gp.close()
+
+
 def secondary(a):
     """The two other GPU configurations of BASELINE.json on their own, same launch contract and JSON shape."""
     import torch.distributed as dist
@@ -434,7 +500,13 @@ def main():
     ap.add_argument('--replicas', action='store_true', help='cfg4 with several GPUs: independent loops instead of one sharded loop')
     ap.add_argument('--settings', type=int, default=0, help='cfg5: settings per GPU (default 256 / gpus)')
     ap.add_argument('--rehearse', action='store_true', help='launch/exchange plumbing only, on the CPU (no GPU work, no measurement)')
+    ap.add_argument('--single-process', action='store_true',
+                    help='drive the --gpus GPUs from this one process through the multi-context handle (cfg2 / cfg3 sweep)')
     a = ap.parse_args()
+    if a.single_process and 'WORLD_SIZE' not in os.environ:
+        if a.config not in ('cfg2', 'cfg3'):
+            sys.exit('bench.py: --single-process measures the candidate sweep (cfg2 / cfg3)')
+        return single_process(a)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a.gpus))
     if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != a.gpus:
@@ -464,6 +536,15 @@ def main():
         if rank == 0:
             out['cfg3'] = {k: blk[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'config', 'roofline',
                                                'phases_ms_per_step', 'phase_rooflines', 'fit', 'end_to_end', 'argmax')}
+        if world > 1:
+            # the north-star split: ONE candidate set of that model (a bounded 524288-candidate slice of the 64 M) divided
+            # over the ranks; rank 0 fits, the model goes out over every link, and the end-to-end figure carries both
+            a2 = argparse.Namespace(**vars(a))
+            a2.scaling, a2.m = 'strong', 1 << 19
+            blk = sweep_block(a2, 'cfg3', gp, world, rank, backend, steps=1, warmup=0, with_cpu=False)
+            if rank == 0:
+                out['cfg3_strong'] = {k: blk[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'config',
+                                                          'roofline', 'phases_ms_per_step', 'fit', 'end_to_end', 'argmax')}
     gp.close()
     if a.config == 'cfg2' and not a.no_cfg45 and not a.n and not a.m:
         # the two remaining GPU configurations, each in a context of its own: the 64^4-lattice loop (200 iterations) and 32

@@ -119,3 +119,45 @@ def test_two_rank_sharded_lml_gathers_every_setting():
     nll, g, stat = _FakeGP().lml_batch(None, None, thetas, sigmas, grad=True)
     for r in res:
         assert np.array_equal(r[1], nll, equal_nan=True) and np.array_equal(r[2], g, equal_nan=True) and np.array_equal(r[3], stat)
+
+
+def _scatter_worker(rank, world, port, q, src, length):
+    import torch
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ref = torch.arange(length, dtype=torch.float64) * 0.5 + 1.0
+        t = ref.clone() if rank == src else torch.full((length,), -1.0, dtype=torch.float64)
+        gdist.scatter_allgather(t, src)
+        # max over ranks with numpy's NaN rule: rank 1 contributes a NaN in the second call only
+        a = gdist.allreduce_max(float(rank))
+        b = gdist.allreduce_max(float('nan') if rank == 1 else 7.0)
+        q.put((rank, bool(torch.equal(t, ref)), a, b))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scatter_allgather_hands_every_rank_the_whole_tensor():
+    """The inverse factor goes out in world - 1 slices (one per link of the root) and is completed among the receivers;
+    lengths that do not divide, fewer elements than slices, and a root other than rank 0 included."""
+    ctx = mp.get_context('spawn')
+    for world, src, length in ((2, 0, 1000), (3, 0, 1001), (4, 2, 10), (4, 0, 2)):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, q, src, length)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for r in res:
+            assert r[1], (world, src, length, r[0])
+            assert r[2] == world - 1 and np.isnan(r[3])
+
+
+def test_slice_bounds_tile_the_range():
+    for n in (0, 1, 5, 1 << 20):
+        for parts in (1, 2, 3, 7):
+            edges = [gdist.slice_bounds(n, parts, s) for s in range(parts)]
+            assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[i][1] == edges[i + 1][0] for i in range(parts - 1))
