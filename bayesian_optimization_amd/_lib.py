@@ -65,6 +65,8 @@ SIGNATURES = {
     'gpbo_append': (C.c_int, [C.c_void_p, _dp, C.c_double, _dp]),
     'gpbo_append_acquire': (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_int32, C.c_double, C.c_int32, C.c_double, _dp, _i64p, _dp]),
     'gpbo_kriging_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, C.c_double, C.c_int32, _dp, _i32p, _dp]),
+    'gpbo_kriging_cross_scale': (C.c_int, [C.c_void_p, _dp, C.c_double]),
+    'gpbo_kriging_lml': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double, _dp, _i32p]),
     'gpbo_set_posterior': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
     'gpbo_kernel_matrix': (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, C.c_int32, _dp, C.c_int32, _dp]),
     'gpbo_kernel_from_distances': (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, _dp, C.c_int32, _dp]),

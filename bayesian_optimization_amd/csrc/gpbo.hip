@@ -16,8 +16,10 @@
 
 #include "../../include/gpbo.h"
 #include "kernels.hpp"
+#include "lu.hpp"
 
-#define GPBO_VARIANT_KRIGING 2   /* trend GP of Gaussian_Process_Regression.ipynb:197-234 (internal tag) */
+#define GPBO_VARIANT_KRIGING 2      /* trend GP of Gaussian_Process_Regression.ipynb:197-234 (internal tag) */
+#define GPBO_VARIANT_KRIGING_LU 4   /* the same model solved through LU with partial pivoting: bufW holds the full inverse */
 
 using namespace gpbo;
 
@@ -82,6 +84,9 @@ struct gpbo_ctx {
     int batch = 1;              // > 1: a batched context, every model buffer holds `batch` slots (see BatchStride)
     BatchStride bs;
     gpbo_ctx* lml_lock = nullptr;   // the batched work context of the likelihood sweep (caller context only)
+    gpbo_ctx* kr_work = nullptr;    // private work context of gpbo_kriging_lml (caller context only)
+    int* ipiv = nullptr;            // row exchanges of the LU fallback of the trend flavour (n_pad ints)
+    int64_t ipiv_cap = 0;
 
     // work contexts of the batched likelihood sweep (created on first use, kept for the next call)
     std::vector<gpbo_ctx*> lml_lanes;
@@ -138,6 +143,10 @@ namespace {
     } while (0)
 
 int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// Largest padded size for which the trend flavour falls back to LU when its matrix is not positive definite: the explicit
+// inverse of that path is formed by one thread per column (n^2 sequential steps each).
+constexpr int64_t KRIGING_LU_MAX = 8192;
 
 hipEvent_t ev_get(gpbo_ctx* ctx) {
     if (ctx->pool_used == ctx->pool.size()) {
@@ -572,7 +581,11 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                 int cg = std::min(nj, 128);   // column blocks per tile-order group
                 if (const char* e = getenv("GPBO_TRMM_COLGROUP")) cg = std::max(1, std::min(nj, atoi(e)));
                 // tile engine mode 2: priority raised over each MFMA burst, LDS fragments requested one k-substep ahead
-                if (keep_v)
+                if (ctx->variant == GPBO_VARIANT_KRIGING_LU)      // bufW is the full inverse: r^T Kinv r per candidate
+                    hipLaunchKernelGGL(k_gemm_dot, dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
+                                       (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
+                                       ctx->partial, nb, nj, cg);
+                else if (keep_v)
                     hipLaunchKernelGGL((k_trmm_sumsq<true, 2>), dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n, cg);
@@ -898,6 +911,10 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     ctx->lml_lanes.clear();
     if (ctx->lml_lock) gpbo_destroy(ctx->lml_lock);
     ctx->lml_lock = nullptr;
+    if (ctx->kr_work) gpbo_destroy(ctx->kr_work);
+    ctx->kr_work = nullptr;
+    if (ctx->ipiv) hipFree(ctx->ipiv);
+    ctx->ipiv = nullptr;
     free_model(ctx);
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
                   ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
@@ -1328,13 +1345,15 @@ int gpbo_append_acquire(gpbo_ctx* ctx, const double* x_new, double y_new, int32_
     return append_acquire_impl(ctx, x_new, y_new, acq, kappa, incumbent_mode, incumbent, mu_max_out, argmax_out, best_out);
 }
 
-int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, double theta, int32_t deg,
-                     double* beta_out, int32_t* nbeta_out, double* cov_out) {
-    if (!ctx) return GPBO_ERR_BAD_ARG;
+// gpr_poly on the device (see gpbo_kriging_fit).  mle_epsilon != nullptr: also the quantity gpr_mle returns
+// (Gaussian_Process_Regression.ipynb:255-263) into *mle_out, which needs a second factorisation, of K + epsilon I.
+static int kriging_fit_impl(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, double theta, int32_t deg,
+                            double* beta_out, int32_t* nbeta_out, double* cov_out, const double* mle_epsilon, double* mle_out) {
     if (!X || !y) BADARG("kriging_fit: null input");
     if (n <= 0 || d <= 0 || d > 3) BADARG("kriging_fit: the trend basis exists for 1..3 input columns");
     if (deg < 0) BADARG("kriging_fit: negative degree");
     if (!(theta != 0.0) || !std::isfinite(theta)) BADARG("kriging_fit: theta must be finite and non-zero");
+    if (mle_epsilon && !(*mle_epsilon >= 0.0)) BADARG("kriging_lml: epsilon must be >= 0");
     // number of trend columns, as polymat builds them
     int p = 1;
     if (deg >= 1) p = 1 + d;
@@ -1380,54 +1399,78 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
         for (int64_t i = 0; i < n; ++i) rhs[(size_t)c * n_pad + i] = trend_col(i, c);
     for (int64_t i = 0; i < n; ++i) rhs[(size_t)p * n_pad + i] = y[i];
     double *rhs_dev = nullptr, *u_dev = nullptr, *x_dev = nullptr;
-    auto cleanup = [&]() {
-        for (void* ptr : {(void*)rhs_dev, (void*)u_dev, (void*)x_dev})
-            if (ptr) hipFree(ptr);
-    };
-    if (hipMalloc((void**)&rhs_dev, rhs.size() * 8) != hipSuccess || hipMalloc((void**)&u_dev, rhs.size() * 8) != hipSuccess ||
-        hipMalloc((void**)&x_dev, rhs.size() * 8) != hipSuccess) {
-        cleanup();
-        ctx->err = "kriging_fit: hipMalloc failed";
-        return GPBO_ERR_HIP;
-    }
-    hipError_t up = hipMemcpyAsync(ctx->Xts, xts.data(), xts.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (up == hipSuccess) up = hipMemcpyAsync(ctx->params, par.data(), par.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (up == hipSuccess) up = hipMemcpyAsync(rhs_dev, rhs.data(), rhs.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (up == hipSuccess) up = hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream);
-    if (up == hipSuccess) up = hipStreamSynchronize(ctx->stream);
-    if (up != hipSuccess) {
-        cleanup();
-        ctx->err = std::string("kriging_fit: upload failed: ") + hipGetErrorString(up);
-        return GPBO_ERR_HIP;
-    }
+    struct Guard {      // the three work vectors are released on every way out
+        double *&a, *&b, *&c;
+        ~Guard() {
+            for (double* ptr : {a, b, c})
+                if (ptr) hipFree(ptr);
+        }
+    } guard{rhs_dev, u_dev, x_dev};
+    HIPCHK(hipMalloc((void**)&rhs_dev, rhs.size() * 8));
+    HIPCHK(hipMalloc((void**)&u_dev, rhs.size() * 8));
+    HIPCHK(hipMalloc((void**)&x_dev, rhs.size() * 8));
+    HIPCHK(hipMemcpyAsync(ctx->Xts, xts.data(), xts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->params, par.data(), par.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(rhs_dev, rhs.data(), rhs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     timing_begin(ctx);
-    int st = GPBO_OK;
+    int info = 0;
+    bool use_lu = false;
     {
         Scope tot(ctx, T_TOTAL);
-        st = launch_kernel_matrix(ctx, ctx->bufA, nullptr, 0.0);
-        if (st == GPBO_OK) st = launch_cholesky(ctx, ctx->bufA, ctx->info_dev);
-        if (st == GPBO_OK) st = launch_inverse(ctx, ctx->bufA, ctx->bufW, ctx->bufB);
-        if (st == GPBO_OK) {
+        CHK(launch_kernel_matrix(ctx, ctx->bufA, nullptr, 0.0));
+        CHK(launch_cholesky(ctx, ctx->bufA, ctx->info_dev));
+        HIPCHK(hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (info == 0) {
+            CHK(launch_inverse(ctx, ctx->bufA, ctx->bufW, ctx->bufB));
             hipLaunchKernelGGL(k_tri_gemv_n, dim3((unsigned)((n + 3) / 4), (unsigned)q), dim3(256), 0, ctx->stream,
                                (const double*)ctx->bufW, (long)n_pad, (int)n, (const double*)rhs_dev, u_dev, (int)n_pad);
             hipLaunchKernelGGL(k_tri_gemv_t, dim3((unsigned)((n + 255) / 256), (unsigned)q), dim3(256), 0, ctx->stream,
                                (const double*)ctx->bufW, (long)n_pad, (int)n, (const double*)u_dev, x_dev, (int)n_pad);
+        } else if (n_pad <= KRIGING_LU_MAX) {
+            // K without jitter is not numerically positive definite: the reference's np.linalg.solve (LU with partial
+            // pivoting) still returns numbers there.  Same route: P K = L U, the explicit inverse into bufW, solves by
+            // multiplication with it.
+            use_lu = true;
+            ctx->variant = GPBO_VARIANT_KRIGING_LU;
+            if (ctx->ipiv_cap < n_pad) {
+                if (ctx->ipiv) hipFree(ctx->ipiv);
+                ctx->ipiv = nullptr;
+                ctx->ipiv_cap = 0;
+                HIPCHK(hipMalloc((void**)&ctx->ipiv, (size_t)n_pad * sizeof(int)));
+                ctx->ipiv_cap = n_pad;
+            }
+            HIPCHK(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+            CHK(launch_kernel_matrix(ctx, ctx->bufA, nullptr, 0.0));
+            hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)(n_pad / 64), (unsigned)(n_pad / 4)), dim3(256), 0, ctx->stream, ctx->bufA, (int)n_pad);
+            const int nb = (int)ctx->nb;
+            for (int pp = 0; pp < nb; ++pp) {
+                const int c0 = pp * PB;
+                hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), 0, ctx->stream, ctx->bufA, (long)n_pad, (int)n_pad, c0, ctx->ipiv, ctx->info_dev);
+                if (nb > 1)
+                    hipLaunchKernelGGL(k_lu_swap_rows, dim3((unsigned)((n_pad - PB + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufA,
+                                       (long)n_pad, (int)n_pad, c0, (const int*)ctx->ipiv);
+                if (pp + 1 < nb) {
+                    hipLaunchKernelGGL(k_lu_trsm_u, dim3((unsigned)((n_pad - c0 - PB + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufA,
+                                       (long)n_pad, (int)n_pad, c0);
+                    hipLaunchKernelGGL(k_lu_gemm_update, dim3((unsigned)(nb - pp - 1), (unsigned)(nb - pp - 1)), dim3(GEMM_THREADS), 0,
+                                       ctx->stream, ctx->bufA, (long)n_pad, pp);
+                }
+            }
+            hipLaunchKernelGGL(k_lu_inverse_cols, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->bufA,
+                               (long)n_pad, (int)n_pad, (const int*)ctx->ipiv, ctx->bufW);
+            hipLaunchKernelGGL(k_full_gemv, dim3((unsigned)((n + 3) / 4), (unsigned)q), dim3(256), 0, ctx->stream, (const double*)ctx->bufW,
+                               (long)n_pad, (int)n, (const double*)rhs_dev, x_dev, (int)n_pad);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         }
     }
-    if (st != GPBO_OK) {
-        cleanup();
-        return st;
-    }
+    HIPCHK(hipGetLastError());
     std::vector<double> sol((size_t)q * n_pad);
-    int info = 0;
-    hipError_t e1 = hipMemcpyAsync(sol.data(), x_dev, sol.size() * 8, hipMemcpyDeviceToHost, ctx->stream);
-    hipError_t e2 = hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    hipError_t e3 = hipStreamSynchronize(ctx->stream);
-    cleanup();
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-        ctx->err = "kriging_fit: device copy failed";
-        return GPBO_ERR_HIP;
-    }
+    if (info == 0 || use_lu) HIPCHK(hipMemcpyAsync(sol.data(), x_dev, sol.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     double ms[T_NCAT], cnt[T_NCAT];
     timing_collect(ctx, ms, cnt);
     ctx->tm.fit_total_ms = ms[T_TOTAL];
@@ -1437,7 +1480,8 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
     ctx->tm.inverse_ms = ms[T_INV];
     if (info != 0) {
         ctx->info = info;
-        ctx->err = "kriging_fit: K is not positive definite (no jitter is added in this flavour)";
+        ctx->err = use_lu ? "kriging_fit: K is singular (an exactly zero pivot column in the LU factorisation)"
+                          : "kriging_fit: K is not positive definite (no jitter is added in this flavour) and too large for the LU fallback";
         return GPBO_ERR_NOT_PD;
     }
     // GLS trend on the host (p <= 10): beta = (F^T K^-1 F)^-1 F^T K^-1 y, :201
@@ -1453,7 +1497,6 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
         b[r] = s3;
     }
     {   // Gaussian elimination with partial pivoting (what np.linalg.solve does for this p x p system)
-        std::vector<int> piv(p);
         for (int c = 0; c < p; ++c) {
             int best = c;
             for (int r = c + 1; r < p; ++r)
@@ -1480,7 +1523,7 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
     }
     // a = K^-1 (y - F beta), cov = (y - F beta)^T a / n  (:202)
     std::vector<double> a(n_pad, 0.0);
-    double cov = 0;
+    double cov = 0, rr = 0;
     for (int64_t i = 0; i < n; ++i) {
         double ai = sol[(size_t)p * n_pad + i], ri = y[i];
         for (int c = 0; c < p; ++c) {
@@ -1489,6 +1532,7 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
         }
         a[i] = ai;
         cov += ri * ai;
+        rr += ri * ri;
     }
     cov /= (double)n;
     par[P_THETA1] = cov;
@@ -1510,11 +1554,83 @@ int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n,
     ctx->y_max = ymax;
     ctx->bufL = ctx->bufA;
     ctx->fitted = true;
-    ctx->have_factor = true;
+    ctx->have_factor = !use_lu;              // the LU path has no Cholesky factor to hand out
     ctx->reserve_left = 0;
     if (beta_out) memcpy(beta_out, beta.data(), p * sizeof(double));
     if (nbeta_out) *nbeta_out = p;
     if (cov_out) *cov_out = cov;
+    if (mle_epsilon) {
+        // gpr_mle (:255-263): 1/2 log det chol(K + epsilon I) + r^T r / (2 cov^2) + N/2 log(2 pi cov^2); the determinant of the
+        // triangular factor as the sum of the logs of its diagonal (the reference multiplies the diagonal out, which
+        // underflows for a few hundred points).  K + epsilon I is factored in bufB; a pivot <= 0 is the LinAlgError
+        // np.linalg.cholesky raises there.
+        HIPCHK(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+        CHK(launch_kernel_matrix(ctx, ctx->bufB, nullptr, *mle_epsilon));
+        CHK(launch_cholesky(ctx, ctx->bufB, ctx->info_dev));
+        hipLaunchKernelGGL(k_sumlog_diag, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->bufB, (long)n_pad, (int)n, ctx->red_v);
+        HIPCHK(hipGetLastError());
+        double sumlog = 0;
+        int info2 = 0;
+        HIPCHK(hipMemcpyAsync(&sumlog, ctx->red_v, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&info2, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (info2 != 0) {
+            ctx->info = info2;
+            ctx->err = "kriging_lml: K + epsilon I is not positive definite";
+            return GPBO_ERR_NOT_PD;
+        }
+        if (mle_out) *mle_out = 0.5 * sumlog + rr / (2.0 * cov * cov) + 0.5 * (double)n * std::log(2.0 * M_PI * cov * cov);
+    }
+    return GPBO_OK;
+}
+
+int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, double theta, int32_t deg,
+                     double* beta_out, int32_t* nbeta_out, double* cov_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    return kriging_fit_impl(ctx, X, y, n, d, theta, deg, beta_out, nbeta_out, cov_out, nullptr, nullptr);
+}
+
+int gpbo_kriging_cross_scale(gpbo_ctx* ctx, const double* X, double theta_r) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!X) BADARG("kriging_cross_scale: null input");
+    if (!ctx->fitted || (ctx->variant != GPBO_VARIANT_KRIGING && ctx->variant != GPBO_VARIANT_KRIGING_LU))
+        BADARG("kriging_cross_scale: call gpbo_kriging_fit first");
+    if (!(theta_r != 0.0) || !std::isfinite(theta_r)) BADARG("kriging_cross_scale: theta_r must be finite and non-zero");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int d = ctx->d;
+    const int64_t n = ctx->n, n_pad = ctx->n_pad;
+    std::vector<double> xts((size_t)d * n_pad, 0.0), it((size_t)d, 1.0 / theta_r);
+    for (int t = 0; t < d; ++t)
+        for (int64_t i = 0; i < n; ++i) xts[(size_t)t * n_pad + i] = X[i * d + t] / theta_r;
+    HIPCHK(hipMemcpyAsync(ctx->Xts, xts.data(), xts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->params + P_INVTHETA, it.data(), it.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->theta.assign((size_t)d, theta_r);
+    ctx->have_posterior = false;
+    ctx->have_acq = false;
+    return GPBO_OK;
+}
+
+int gpbo_kriging_lml(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, const double* thetas, int32_t B,
+                     int32_t deg, double epsilon, double* nll_out, int32_t* status_out) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!thetas || !nll_out || B <= 0) BADARG("kriging_lml: need B >= 1 and non-null arrays");
+    if (!ctx->kr_work && gpbo_create(ctx->device, &ctx->kr_work) != GPBO_OK) {
+        ctx->err = "kriging_lml: could not create the work context";
+        return GPBO_ERR_HIP;
+    }
+    gpbo_ctx* w = ctx->kr_work;      // private: the caller's model, candidates and posterior are untouched
+    w->timing_off = true;
+    for (int b = 0; b < B; ++b) {
+        double v = NAN;
+        const int st = kriging_fit_impl(w, X, y, n, d, thetas[b], deg, nullptr, nullptr, nullptr, &epsilon, &v);
+        if (st == GPBO_ERR_BAD_ARG || st == GPBO_ERR_HIP) {
+            ctx->err = w->err;
+            return st;
+        }
+        nll_out[b] = (st == GPBO_OK) ? v : NAN;
+        if (status_out) status_out[b] = st;
+    }
     return GPBO_OK;
 }
 

@@ -190,6 +190,26 @@ class GP:
         self.theta1, self.nll = cov.value, float('nan')
         return beta[:nb.value].copy(), cov.value
 
+    def kriging_cross_scale(self, xT, theta_r):
+        """y_kriging / mse_kriging: correlation vectors with length scale theta_r = sqrt(w0) against the fitted K."""
+        X = _f64(xT, 2)
+        if X.shape != (self.n, self.d):
+            raise ValueError('xT must be the (%d, %d) training inputs of the fit' % (self.n, self.d))
+        self._check(self._lib.gpbo_kriging_cross_scale(self._h, L.dptr(X), float(theta_r)))
+
+    def kriging_lml(self, xT, yT, thetas, deg, epsilon):
+        """gpr_mle (Gaussian_Process_Regression.ipynb:255-263) for every theta in thetas: (values (B,), status (B,))."""
+        X = _f64(xT, 2)
+        y = _f64(np.asarray(yT).reshape(-1), 1)
+        th = _f64(np.asarray(thetas).reshape(-1), 1)
+        if y.shape[0] != X.shape[0]:
+            raise ValueError('xT has %d rows, yT %d' % (X.shape[0], y.shape[0]))
+        out = np.empty(th.shape[0])
+        stat = np.zeros(th.shape[0], dtype=np.int32)
+        self._check(self._lib.gpbo_kriging_lml(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1], L.dptr(th), th.shape[0],
+                                               int(deg), float(epsilon), L.dptr(out), stat.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out, stat
+
     def set_posterior(self, mu, var):
         """Upload a (mu, diag(Cov)) pair so acquire() can evaluate an acquisition on it."""
         mu = _f64(np.asarray(mu).reshape(-1), 1)
@@ -569,6 +589,13 @@ class MultiGP:
 
     def descent_small(self, *args, **kwargs):
         return self.contexts[0].descent_small(*args, **kwargs)
+
+    def kriging_lml(self, *args, **kwargs):
+        return self.contexts[0].kriging_lml(*args, **kwargs)
+
+    def kriging_cross_scale(self, xT, theta_r):
+        for g in self.contexts:
+            g.kriging_cross_scale(xT, theta_r)
 
 
 def device_count():

@@ -209,3 +209,41 @@ def hypopt_wrap(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain,
     iopt = int(np.argmin(ff))
     last = param_cont[iopt][-1] if np.isfinite(cost_cont[iopt][-1]) else param_cont[iopt][-2]
     return last
+
+
+def gpr_descent(xT, yT, deg, epsilon, alpha, beta, max_its, W0, fd_h=1e-6, device=None):
+    """The GPR notebook's hyper-parameter fit (Gaussian_Process_Regression.ipynb:473-510, :621-660): its own
+    conj_gradient_descent (:45-100; no stopping test, max_its - 1 steps, histories of max_its entries) on gpr_mle (:255-263)
+    with norm = 'component' and the constant step, every start of W0 (nruns,) in lockstep.  The notebook differentiates
+    gpr_mle with autograd; under the 'component' rule only the SIGN of the derivative enters the step, and here it comes
+    from a central difference of the device-evaluated gpr_mle, (f(w + h|w|) - f(w - h|w|)) / (2 h |w|): one library call per
+    iteration evaluates the three points of every start.  Returns (weight_history, cost_history) as lists per start.  A
+    start whose next point cannot be evaluated (K + epsilon I not positive definite) keeps its last point, cost +inf."""
+    gp = _lml_gp(device)
+    w = np.array(W0, dtype=np.float64, copy=True).reshape(-1)
+    nruns = w.shape[0]
+
+    def evaluate(pts):
+        h = fd_h * np.abs(pts)
+        vals, stat = gp.kriging_lml(xT, yT, np.concatenate([pts, pts + h, pts - h]), deg, epsilon)
+        vals = np.where(stat == 0, vals, np.inf)
+        f0, fp, fm = vals[:nruns], vals[nruns:2 * nruns], vals[2 * nruns:]
+        with np.errstate(invalid='ignore'):
+            g = (fp - fm) / (2 * h)
+        return f0, np.where(np.isfinite(g), g, 0.0)
+
+    cost, grad = evaluate(w)
+    w_hist = [[np.array([w[r]])] for r in range(nruns)]
+    c_hist = [[cost[r]] for r in range(nruns)]
+    dtemp = np.zeros(nruns)
+    for k in range(1, int(max_its)):
+        d = (1 - beta) * dtemp + beta * np.sign(grad) * 1.0      # sqrt(len(w0)) = 1: theta is a scalar in this flavour
+        wn = w - alpha * d
+        ok = np.isfinite(wn) & (wn != 0.0)
+        wn = np.where(ok, wn, w)
+        cost, grad = evaluate(wn)
+        w, dtemp = wn, d
+        for r in range(nruns):
+            w_hist[r].append(np.array([w[r]]))
+            c_hist[r].append(cost[r])
+    return w_hist, c_hist

@@ -4,7 +4,7 @@
 
 Reference signatures (BayesOpt/BayesOpt_v4.ipynb): distmat_v2 :100, kernfcn_v2 :119, gprfcn :127,
 mlefcn :154, expected_improvement :188; (BayesOpt/Gaussian_Process_Regression.ipynb): polymat :113,
-gpr_poly :197, y_kriging_v2 :228, acquisition :265.
+gpr_poly :197, y_kriging :205, y_kriging_v2 :228, mse_kriging :236, gpr_mle :255, acquisition :265.
 
 Deliberate differences, all at sizes/outputs no caller in the reference consumes:
   * gprfcn returns Cov as a ``DiagCov``: np.diag(Cov) / Cov.diagonal() give the (m,) variance the callers
@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _lib as L
 from .gp import GP, make_gp
-from .hyperopt import hypopt, hypopt_wrap  # noqa: F401  (BayesOpt_v4.ipynb:167-186, batched over the starts)
+from .hyperopt import gpr_descent, hypopt, hypopt_wrap  # noqa: F401  (BayesOpt_v4.ipynb:167-186, batched over the starts)
 from .loop import bayes_opt  # noqa: F401  (the while loop of BayesOpt_v4.ipynb:618-664)
 
 _ctx = {}
@@ -248,25 +248,71 @@ def gpr_poly(xT, yT, xS, theta, kernel, deg):
     K = KrigingK(xT, xT, thv)
     K._fit_key = (xT.tobytes(), np.asarray(yT, dtype=np.float64).tobytes(), th, int(deg))
     gp._kr_key = K._fit_key
+    gp._kr_cross = None
     Ks = KernelHandle(xT, xS, thv)
     Kss = KernelHandle(xT, xT, thv)       # the reference builds Kss from DTT as well (:177)
     return beta, cov, K, Ks, Kss, polymat(xT, deg), polymat(xS, deg)
 
 
-def y_kriging_v2(x, beta, cov, K, FT, xT, yT, theta, deg, kernel):
-    """mu, mse for one point (the notebook's usage) or a batch of points x (m, d)."""
+def _kriging_context(xT, yT, th, deg):
+    """The 'kriging' context fitted to (xT, yT, th, deg): reused when the last fit was this one."""
     gp = _gp('kriging')
-    xT = np.ascontiguousarray(xT, dtype=np.float64)
-    x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
-    th = float(np.squeeze(theta))
     key = (xT.tobytes(), np.asarray(yT, dtype=np.float64).tobytes(), th, int(deg))
-    if getattr(gp, '_kr_key', None) != key:
+    if getattr(gp, '_kr_key', None) != key or getattr(gp, '_kr_cross', None) is not None:
         gp.kriging_fit(xT, yT, th, deg)
         gp._kr_key = key
+        gp._kr_cross = None
+    return gp
+
+
+def y_kriging_v2(x, beta, cov, K, FT, xT, yT, theta, deg, kernel):
+    """mu, mse for one point (the notebook's usage) or a batch of points x (m, d)."""
+    xT = np.ascontiguousarray(xT, dtype=np.float64)
+    x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+    gp = _kriging_context(xT, yT, float(np.squeeze(theta)), deg)
     gp.set_candidates(x)
     gp.posterior()
     mu, mse = gp.read()
     return mu, mse
+
+
+def _kriging_w(x, K, xT, yT, theta, deg, kernel):
+    """y_kriging / mse_kriging share this: r = exp(-d^2 / (2 w0)), w0 = theta[0] (the 'gaussian' branch, :212-214), against
+    the K gpr_poly built -- K must be the handle gpr_poly returned (it names the fit)."""
+    if kernel != 'gaussian':
+        raise NotImplementedError("only the 'gaussian' branch is built (the others are not used by any executed cell)")
+    if not isinstance(K, KrigingK):
+        raise TypeError('K must be the matrix handle gpr_poly returned')
+    xT = np.ascontiguousarray(xT, dtype=np.float64)
+    x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+    th_K, deg_K = K._fit_key[2], K._fit_key[3]
+    gp = _kriging_context(xT, yT, th_K, deg_K)
+    w0 = float(np.asarray(theta, dtype=np.float64).reshape(-1)[0])
+    gp.kriging_cross_scale(xT, np.sqrt(w0))
+    gp._kr_cross = w0
+    gp.set_candidates(x)
+    gp.posterior()
+    return gp.read()
+
+
+def y_kriging(x, beta, K, FT, xT, yT, theta, deg, kernel):
+    """Gaussian_Process_Regression.ipynb:205-226.  The reference reads the process variance from a global named cov
+    (:224); here it is the cov of the fit K belongs to."""
+    return _kriging_w(x, K, xT, yT, theta, deg, kernel)
+
+
+def mse_kriging(x, cov, K, FT, xT, yT, theta, deg, kernel):
+    """Gaussian_Process_Regression.ipynb:236-253 (cov as gpr_poly returned it)."""
+    return _kriging_w(x, K, xT, yT, theta, deg, kernel)[1]
+
+
+def gpr_mle(theta, xT, yT, xS, kernel, deg, epsilon):
+    """Gaussian_Process_Regression.ipynb:255-263: the value the notebook's descent minimises (xS and kernel are accepted
+    for the signature: the model is the 'gaussian' gpr_kernel_v2 one, :173-178, and xS does not enter the value)."""
+    val, stat = _gp('kriging').kriging_lml(np.ascontiguousarray(xT, dtype=np.float64), yT, [float(np.squeeze(theta))], deg, epsilon)
+    if stat[0] != 0:
+        raise np.linalg.LinAlgError('Matrix is not positive definite')
+    return float(val[0])
 
 
 def acquisition(mu, yT, sigma):
@@ -280,4 +326,4 @@ def acquisition(mu, yT, sigma):
 
 
 __all__ = ['distmat_v2', 'kernfcn_v2', 'gprfcn', 'mlefcn', 'expected_improvement', 'hypopt', 'hypopt_wrap', 'polymat', 'gpr_poly', 'y_kriging_v2',
-           'acquisition']
+           'y_kriging', 'mse_kriging', 'gpr_mle', 'gpr_descent', 'acquisition', 'bayes_opt']

@@ -178,9 +178,29 @@ int gpbo_append_acquire(gpbo_ctx* ctx, const double* x_new, double y_new, int32_
  * beta (:201), cov = r^T K^-1 r / n (:202).  beta_out must hold 10 doubles.  After it,
  * gpbo_set_candidates + gpbo_posterior give y_kriging_v2 (:228-234) for every candidate:
  * mu = f beta + r^T K^-1 (y - F beta) and, in the variance slot, mse = cov^2 (1 - r^T K^-1 r)
- * (not clamped, as in the reference). */
+ * (not clamped, as in the reference).
+ * K is factored by Cholesky; when a pivot is not positive (K without jitter is often not numerically positive definite:
+ * the notebook's own 3-D cell, :811-874, has cond(K) = 4e19) the call falls back, for n <= 8192, to LU with partial pivoting
+ * and the explicit inverse -- the route of the reference's np.linalg.solve -- and returns numbers wherever the reference
+ * does (GPBO_ERR_NOT_PD only for an exactly singular matrix, numpy's "Singular matrix").  What those numbers are worth
+ * at such a condition number is another matter: the reference's own are not reproducible there either. */
 int gpbo_kriging_fit(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, double theta,
                      int32_t deg, double* beta_out, int32_t* nbeta_out, double* cov_out);
+
+/* gpr_mle (Gaussian_Process_Regression.ipynb:255-263), the function the GPR notebook's descent minimises (:476, :622), for B
+ * values of theta:  1/2 log det chol(K + epsilon I) + r^T r / (2 cov^2) + n/2 log(2 pi cov^2),  r = y - F beta, with beta and
+ * cov from gpr_poly on the un-jittered K (as above, LU fallback included); epsilon only enters the factor whose
+ * determinant is taken.  nll_out (B,); status_out (B,) may be NULL: GPBO_ERR_NOT_PD (and nll = NaN) where K + epsilon I has a
+ * non-positive pivot (np.linalg.cholesky raises there) or K is exactly singular.  Runs in a private work context:
+ * the model, candidates and posterior of ctx are untouched. */
+int gpbo_kriging_lml(gpbo_ctx* ctx, const double* X, const double* y, int64_t n, int32_t d, const double* thetas, int32_t B,
+                     int32_t deg, double epsilon, double* nll_out, int32_t* status_out);
+
+/* y_kriging / mse_kriging (Gaussian_Process_Regression.ipynb:205-226, :236-253, 'gaussian' branch) evaluate the correlation
+ * vector of a new point with a length scale of their own, r = exp(-d^2 / (2 w0)), against the K that gpr_poly built with
+ * its theta.  After gpbo_kriging_fit, this call makes the candidate sweep use theta_r = sqrt(w0) for r (X: the training
+ * inputs of the fit, (n,d)); the factor of K, beta and cov stay.  The next gpbo_kriging_fit resets it. */
+int gpbo_kriging_cross_scale(gpbo_ctx* ctx, const double* X, double theta_r);
 
 /* Make host arrays (m,) the resident posterior, so gpbo_acquire can run expected_improvement
  * (BayesOpt_v4.ipynb:188-197) / acquisition (Gaussian_Process_Regression.ipynb:265-268) on any Mu, diag(Cov).

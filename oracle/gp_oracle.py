@@ -328,6 +328,50 @@ def kriging_predict(kst, xS):
     return mu, mse
 
 
+def gpr_mle(theta, xT, yT, deg, epsilon):
+    """gpr_mle of Gaussian_Process_Regression.ipynb:255-263 (the quantity the notebook's descent minimises, :476, :622):
+        -mle = 1/2 log det chol(K + epsilon I) + r^T r / (2 cov^2) + N/2 log(2 pi cov^2),   r = yT - FT beta,
+    beta and cov from gpr_poly on the UN-jittered K (LU solves); epsilon only enters the Cholesky factor whose determinant
+    is taken.  The reference takes np.linalg.det of the triangular factor (the product of its diagonal, which underflows
+    for a few hundred points); here the sum of the logs of the diagonal."""
+    kst = kriging_fit(xT, yT, theta, deg)
+    N = kst['xT'].shape[0]
+    Lc = np.linalg.cholesky(kst['K'] + epsilon * np.eye(N))
+    res = kst['yT'] - kst['FT'] @ kst['beta']
+    cov = kst['cov']
+    return 0.5 * float(np.sum(np.log(np.diag(Lc)))) + float(res @ res) / (2 * cov ** 2) + N / 2 * math.log(2 * math.pi * cov ** 2)
+
+
+def kriging_predict_w(kst, xS, w0):
+    """y_kriging / mse_kriging of Gaussian_Process_Regression.ipynb:205-226, :236-253, 'gaussian' branch: the correlation
+    vector is r = exp(-d^2 / (2 w0)) -- the variance-like parameterisation, where y_kriging_v2 has exp(-d^2 / (2 theta^2)) --
+    against the K that gpr_poly built with its own theta (kst).  Returns (mu, mse) for a batch of points."""
+    xS = np.asarray(xS, dtype=np.float64)
+    r = kernel_matrix(kst['xT'], xS, np.full(xS.shape[1], math.sqrt(float(w0))), RBF)
+    f = polymat(xS, kst['deg'])
+    mu = f @ kst['beta'] + r.T @ kst['Kir']
+    mse = kst['cov'] ** 2 * (1.0 - np.sum(r * np.linalg.solve(kst['K'], r), axis=0))
+    return mu, mse
+
+
+def gpr_descent(fun, dfun, alpha, beta, max_its, w0):
+    """conj_gradient_descent of Gaussian_Process_Regression.ipynb:45-100 with norm = 'component' and the constant step
+    (the settings of the notebook's cells, :479-486, :625-632): max_its - 1 steps of
+        d = (1 - beta) d_prev + beta sign(grad) sqrt(len(w));  w = w - alpha d,
+    no stopping test; returns (weight_history, cost_history), max_its entries each.  dfun stands in for autograd's grad(g)."""
+    w = np.array(w0, dtype=np.float64, copy=True)
+    wh, ch = [w.copy()], [fun(w)]
+    dtemp = 0.0
+    for k in range(1, int(max_its)):
+        g = np.asarray(dfun(w), dtype=np.float64)
+        d = (1 - beta) * dtemp + beta * np.sign(g) * math.sqrt(len(w))
+        w = w - alpha * d
+        wh.append(w.copy())
+        ch.append(fun(w))
+        dtemp = d
+    return wh, ch
+
+
 # --------------------------------------------------------------------------- synthetic inputs
 _M64 = (1 << 64) - 1
 

@@ -178,6 +178,120 @@ def kriging_more(a, gpr):
     run('x7_kriging_singular', xs, ys, np.linspace(0, 1, 25)[:, None] + 0.003, np.array([2.0]), 0)
 
 
+def gpr_notebook_cells(a, gpr):
+    """GPRNB: the inputs of the GPR notebook's own driver cells, with a seeded permutation in place of the unseeded one:
+    1-D, 1200-point curve, nT = 3, deg 0, epsilon 1e-9 (Gaussian_Process_Regression.ipynb:372-388, 405-445, 473-526);
+    2-D, 20 x 20 grid on [-pi, pi]^2, every nsamp-th point of a permutation, deg 1, epsilon 1e-8 (:551-592, 621-694);
+    3-D, 800 of the 20^3 grid points on [-1, 1]^3, deg 0, theta = 1 (:811-874).  Stored: what gpr_poly / y_kriging_v2 /
+    y_kriging + mse_kriging / gpr_mle return, cond(K), and the path of the notebook's descent on gpr_mle with central
+    differences of gpr_mle itself standing in for autograd's gradient."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    ns = {'np': np, 'grad': None}
+    load_cell_defining(os.path.join(a.ref, 'BayesOpt', 'Gaussian_Process_Regression.ipynb'), 'conj_gradient_descent', ns)
+
+    def fd_grad(fun, h=1e-6):
+        return lambda w: np.array([(float(np.squeeze(fun(w + h * np.abs(w)))) - float(np.squeeze(fun(w - h * np.abs(w))))) / (2 * h * abs(float(w[0])))])
+
+    def predict(xT, yT, xS, theta, deg):
+        beta, cov, K, Ks, Kss, FT, FS = gpr['gpr_poly'](xT, yT, xT, theta, 'gaussian', deg)
+        mu, mse = np.zeros(len(xS)), np.zeros(len(xS))
+        for i in range(len(xS)):
+            u, v = gpr['y_kriging_v2'](xS[i][None, :], beta, cov, K, FT, xT, yT, theta, deg, 'gaussian')
+            mu[i], mse[i] = np.squeeze(u), np.squeeze(v)
+        return np.asarray(beta), float(np.squeeze(cov)), K, FT, mu, mse
+
+    def mle_grid(xT, yT, thetas, deg, eps):
+        out = np.zeros(len(thetas))
+        for i, t in enumerate(thetas):
+            out[i] = float(np.squeeze(gpr['gpr_mle'](np.array([t]), xT, yT, xT, 'gaussian', deg, eps)))
+        return out
+
+    def descent(xT, yT, deg, eps, w0s, max_its):
+        fun = lambda w: gpr['gpr_mle'](w, xT, yT, xT, 'gaussian', deg, eps)
+        W, Cst = np.zeros((len(w0s), max_its)), np.zeros((len(w0s), max_its))
+        for r, w0 in enumerate(w0s):
+            ns['grad'] = lambda g: fd_grad(g)
+            wh, ch = ns['conj_gradient_descent'](fun, 0.01, 0.5, 'component', 'standard', max_its, np.array([w0]))
+            W[r] = np.squeeze(np.array(wh))
+            Cst[r] = np.squeeze(np.array(ch))
+        return W, Cst
+
+    # ---- 1-D (:372-388): nT = 3 of 1200 points
+    s = np.linspace(-5, 5, 1200)
+    Y = np.exp(-s ** 2) + np.cos(2 * s) * np.sin(2 * s)
+    inds = np.random.default_rng(1001).permutation(1200)
+    xT, yT = s[:, None][inds[:3]], Y[inds[:3]]
+    xS = np.linspace(-5, 5, 1500)[::10][:, None]
+    for theta in (0.5, 1.0):
+        beta, cov, K, FT, mu, mse = predict(xT, yT, xS, np.array([theta]), 0)
+        tg = np.geomspace(0.15, 3.0, 12)
+        w0s = np.array([0.35, 0.62, 0.9])
+        W, Cst = descent(xT, yT, 0, 1e-9, w0s, 100)
+        save(a.out, 'gprnb_1d_theta%s' % ('05' if theta == 0.5 else '1'),
+             dict(xT=xT, yT=yT, xS=xS, theta=np.array([theta]), deg=np.array(0), beta=beta, cov=np.array(cov), mu=mu, mse=mse,
+                  condK=np.array(np.linalg.cond(K)), mle_thetas=tg, mle_eps=np.array(1e-9), mle=mle_grid(xT, yT, tg, 0, 1e-9),
+                  descent_w0=w0s, descent_w=W, descent_cost=Cst, descent_args=np.array([0.01, 0.5, 100])))
+
+    # ---- 2-D (:551-592): 20 x 20 grid on [-pi, pi]^2, theta = 1.05, deg 1
+    N = 20
+    s = np.linspace(-np.pi, np.pi, N)
+    xp = np.array([[s[i], s[j]] for i in range(N) for j in range(N)])
+    yp = (2.5 * np.exp(-(xp[:, 0] ** 2 + xp[:, 1] ** 2)) + np.sin(2 * xp[:, 0]) + np.cos(xp[:, 1]))[:, None]
+    inds = np.random.default_rng(1002).permutation(N * N)
+    s2 = np.linspace(-np.pi, np.pi, 50)
+    xS = np.array([[s2[i], s2[j]] for i in range(0, 50, 3) for j in range(0, 50, 3)])
+    for nsamp in (50, 20, 10, 5, 2):
+        I = inds[::nsamp]
+        xT, yT = xp[I], yp[I]
+        theta = np.array([1.05])
+        beta, cov, K, FT, mu, mse = predict(xT, yT, xS, theta, 1)
+        d = dict(xT=xT, yT=yT, xS=xS, theta=theta, deg=np.array(1), beta=beta, cov=np.array(cov), mu=mu, mse=mse,
+                 condK=np.array(np.linalg.cond(K)))
+        if nsamp >= 10:
+            tg = np.geomspace(0.2, 2.0, 10)
+            d.update(mle_thetas=tg, mle_eps=np.array(1e-8), mle=mle_grid(xT, yT, tg, 1, 1e-8))
+        if nsamp == 20:
+            w0s = np.array([0.5, 1.3])
+            W, Cst = descent(xT, yT, 1, 1e-8, w0s, 120)
+            d.update(descent_w0=w0s, descent_w=W, descent_cost=Cst, descent_args=np.array([0.01, 0.5, 120]))
+        save(a.out, 'gprnb_2d_nsamp%d' % nsamp, d)
+
+    # ---- 3-D (:811-874): 800 of the 20^3 grid points on [-1, 1]^3, theta = 1, deg 0; y_kriging / mse_kriging as the cell calls them
+    s = np.linspace(-1, 1, N)
+    xp = np.array([[s[i], s[j], s[k]] for i in range(N) for j in range(N) for k in range(N)])
+    yp = (np.exp(-(xp ** 2).sum(1) / 10) + np.sin(2 * xp[:, 0]) + np.cos(xp[:, 1]) + 6 * np.cos(xp[:, 2]))[:, None]
+    inds = np.random.default_rng(1003).permutation(N ** 3)
+    I = inds[::10]
+    xT, yT = xp[I], yp[I]
+    s2 = np.linspace(-1, 1, 30)
+    xS = np.array([[s2[i], s2[j], s2[k]] for i in range(0, 30, 6) for j in range(0, 30, 6) for k in range(0, 30, 6)])
+    theta = np.array([1.0])
+    beta, cov, K, FT, mu, mse = predict(xT, yT, xS, theta, 0)
+    gpr['cov'] = cov                                     # y_kriging reads a global named cov (:224)
+    mu_w, mse_w = np.zeros(len(xS)), np.zeros(len(xS))
+    for i in range(len(xS)):
+        u, _ = gpr['y_kriging'](xS[i][None, :], beta, K, FT, xT, yT, theta, 0, 'gaussian')
+        mu_w[i] = np.squeeze(u)
+        mse_w[i] = np.squeeze(gpr['mse_kriging'](xS[i][None, :], cov, K, FT, xT, yT, theta, 0, 'gaussian'))
+    save(a.out, 'gprnb_3d_n800', dict(xT=xT, yT=yT, xS=xS, theta=theta, deg=np.array(0), beta=beta, cov=np.array(cov), mu=mu,
+                                          mse=mse, mu_w=mu_w, mse_w=mse_w, condK=np.array(np.linalg.cond(K))))
+    # the same two functions where K is well conditioned (40 of the points, w0 = 0.09 <-> theta = 0.3)
+    I = inds[:40]
+    xT, yT = xp[I], yp[I]
+    theta = np.array([0.3])
+    beta, cov, K, FT, mu, mse = predict(xT, yT, xS, theta, 0)
+    gpr['cov'] = cov
+    w0 = np.array([0.2])
+    mu_w, mse_w = np.zeros(len(xS)), np.zeros(len(xS))
+    for i in range(len(xS)):
+        u, _ = gpr['y_kriging'](xS[i][None, :], beta, K, FT, xT, yT, w0, 0, 'gaussian')
+        mu_w[i] = np.squeeze(u)
+        mse_w[i] = np.squeeze(gpr['mse_kriging'](xS[i][None, :], cov, K, FT, xT, yT, w0, 0, 'gaussian'))
+    save(a.out, 'gprnb_3d_n40', dict(xT=xT, yT=yT, xS=xS, theta=theta, w0=w0, deg=np.array(0), beta=beta, cov=np.array(cov), mu=mu,
+                                         mse=mse, mu_w=mu_w, mse_w=mse_w, condK=np.array(np.linalg.cond(K))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -190,7 +304,7 @@ def main():
     v4 = load_function_cell(os.path.join(a.ref, 'BayesOpt', 'BayesOpt_v4.ipynb'),
                             ['gprfcn', 'mlefcn', 'expected_improvement'])
     gpr = load_function_cell(os.path.join(a.ref, 'BayesOpt', 'Gaussian_Process_Regression.ipynb'),
-                             ['gpr_poly', 'y_kriging_v2', 'polymat'])
+                             ['gpr_poly', 'y_kriging_v2', 'polymat', 'gpr_mle', 'y_kriging', 'mse_kriging'])
 
     # ---- G1: the .mat mixture data, as the "2D Mixture Data" cells do (BayesOpt_v4.ipynb:681-807)
     mat = scipy.io.loadmat(os.path.join(a.ref, 'BayesOpt', 'GP', 'red3yellow3_4.15.19_processed.mat'))
@@ -222,6 +336,8 @@ def main():
         descent_paths(a, v4, (xT, yT))
     if not only or 'g7more' in only:
         kriging_more(a, gpr)
+    if not only or 'gprnb' in only:
+        gpr_notebook_cells(a, gpr)
     if only and not (only & {'g2', 'g3', 'g4', 'g5', 'g6', 'g7'}):
         return
 

@@ -239,3 +239,51 @@ def test_matlab_two_factor_variant_differs_from_v4_only_through_the_unscaled_noi
     a, _, _ = o.gprfcn_diag(g0['xTest'], g0['xTrain'], g0['yTrain'], g0['theta'], 0.0, variant=o.VARIANT_V4)
     b, _, _ = o.gprfcn_diag(g0['xTest'], g0['xTrain'], g0['yTrain'], g0['theta'], 0.0, variant=o.VARIANT_M3)
     assert relmax(a, b) <= 1e-6
+
+
+# ---- the GPR notebook's own driver-cell inputs (fixtures gprnb_*, written by oracle/make_golden.py from the reference's functions)
+def cond_tol(g, base):
+    """Tolerance for a quantity that goes through K^-1 without jitter: `base` where K is well conditioned, growing with
+    cond(K) * eps where it is not (the reference's own numbers move by that much under one-ulp changes of K's entries)."""
+    return max(base, 30.0 * float(g['condK']) * 2.2e-16)
+
+
+@pytest.mark.parametrize('name', golden_names('gprnb'))
+def test_gpr_notebook_cells_against_the_restatement(name):
+    g = golden(name)
+    if float(g['condK']) > 1e15:
+        pytest.skip('cond(K) = %.1e: the reference\'s LU numbers are not reproducible by any second evaluation' % float(g['condK']))
+    kst = o.kriging_fit(g['xT'], g['yT'], g['theta'], int(g['deg']))
+    mu, mse = o.kriging_predict(kst, g['xS'])
+    assert relmax(kst['beta'], np.squeeze(g['beta']).reshape(-1)) <= cond_tol(g, 1e-11)
+    assert abs(kst['cov'] - float(g['cov'])) <= cond_tol(g, 1e-12) * abs(float(g['cov']))
+    assert relmax(mu, g['mu']) <= cond_tol(g, 1e-12)
+    assert np.max(np.abs(mse - g['mse'])) <= cond_tol(g, 1e-12) * float(g['cov']) ** 2
+    if 'mle' in g.files:
+        m = np.array([o.gpr_mle(t, g['xT'], g['yT'], int(g['deg']), float(g['mle_eps'])) for t in g['mle_thetas']])
+        assert np.max(np.abs(m - g['mle']) / np.abs(g['mle'])) <= 1e-8
+    if 'w0' in g.files:      # y_kriging / mse_kriging with their own parameterisation of r
+        mu_w, mse_w = o.kriging_predict_w(kst, g['xS'], float(g['w0'][0]))
+        assert relmax(mu_w, g['mu_w']) <= 1e-12 and np.max(np.abs(mse_w - g['mse_w'])) <= 1e-12 * float(g['cov']) ** 2
+
+
+def descent_starts_with_a_slope(g):
+    """Starts of a gprnb descent fixture whose path is decided by the function, not by round-off: on the flat part of gpr_mle
+    (tiny theta, K = I to the last bit) the sign of a difference quotient is noise and the reference's own path is arbitrary."""
+    C = g['descent_cost']
+    return [r for r in range(len(g['descent_w0'])) if abs(C[r, 0] - C[r, 5]) > 1e-6 * abs(C[r, 0])]
+
+
+@pytest.mark.parametrize('name', ['gprnb_1d_theta1', 'gprnb_2d_nsamp20'])
+def test_gpr_notebook_descent_path_against_the_restatement(name):
+    g = golden(name)
+    alpha, beta, its = g['descent_args']
+    deg, eps = int(g['deg']), float(g['mle_eps'])
+    fun = lambda w: o.gpr_mle(w[0], g['xT'], g['yT'], deg, eps)
+    dfun = lambda w: np.array([(fun(w + 1e-6 * np.abs(w)) - fun(w - 1e-6 * np.abs(w))) / (2e-6 * abs(w[0]))])
+    rows = descent_starts_with_a_slope(g)
+    assert rows
+    for r in rows:
+        wh, ch = o.gpr_descent(fun, dfun, float(alpha), float(beta), int(its), np.array([g['descent_w0'][r]]))
+        assert np.max(np.abs(np.squeeze(np.array(wh)) - g['descent_w'][r])) <= 1e-9
+        assert np.max(np.abs(np.array(ch) - g['descent_cost'][r]) / np.abs(g['descent_cost'][r])) <= 1e-7
