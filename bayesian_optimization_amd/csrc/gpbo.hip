@@ -19,7 +19,7 @@
 #include "lu.hpp"
 
 #define GPBO_VARIANT_KRIGING 2      /* trend GP of Gaussian_Process_Regression.ipynb:197-234 (internal tag) */
-#define GPBO_VARIANT_KRIGING_LU 4   /* the same model solved through LU with partial pivoting: bufW holds the full inverse */
+#define GPBO_VARIANT_KRIGING_LU 4   /* the same model solved through LU with partial pivoting: bufW holds P K = L U, ipiv the row exchanges */
 
 using namespace gpbo;
 
@@ -106,6 +106,8 @@ struct gpbo_ctx {
     // chunk scratch
     int64_t chunk_req = 0, chunk = 0, scratch_npad = 0;
     double *Bmat = nullptr, *partial = nullptr, *mupart = nullptr;
+    double* Zmat = nullptr;     // LU path of the trend flavour only: the solves of a chunk's correlation vectors (same shape as Bmat)
+    int64_t z_chunk = 0, z_npad = 0;
     int kc = KS_ROWS;   // training rows per workgroup of the Ks build = rows per partial mean
 
     // reductions
@@ -144,8 +146,8 @@ namespace {
 
 int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
-// Largest padded size for which the trend flavour falls back to LU when its matrix is not positive definite: the explicit
-// inverse of that path is formed by one thread per column (n^2 sequential steps each).
+// Largest padded size for which the trend flavour falls back to LU when its matrix is not positive definite (its panel
+// factorisation runs in one workgroup per 128 columns: a fallback, not a fast path).
 constexpr int64_t KRIGING_LU_MAX = 8192;
 
 hipEvent_t ev_get(gpbo_ctx* ctx) {
@@ -526,11 +528,38 @@ int reduce_max(gpbo_ctx* ctx, const double* a, int64_t m, double* dst_dev) {
     return GPBO_OK;
 }
 
+// Z <- K^-1 R for a k-major block R[k][j] (row pitch ldv, `cols` columns, a multiple of 128) with the factors P K = L U
+// held in LU (n_pad x n_pad) and ipiv: Z = R, row exchanges, forward substitution with the unit lower factor and backward
+// substitution with U, block row by block row.
+int launch_lu_solve(gpbo_ctx* ctx, const double* LU, const int* ipiv, const double* R, double* Z, long ldv, int64_t cols) {
+    const long ld = ctx->n_pad;
+    const int nb = (int)ctx->nb, n_pad = (int)ctx->n_pad;
+    HIPCHK(hipMemcpy2DAsync(Z, (size_t)ldv * 8, R, (size_t)ldv * 8, (size_t)cols * 8, (size_t)n_pad, hipMemcpyDeviceToDevice, ctx->stream));
+    const unsigned cblocks = (unsigned)((cols + 255) / 256), ctiles = (unsigned)(cols / TN);
+    hipLaunchKernelGGL(k_lu_permute_rows, dim3(cblocks), dim3(256), 0, ctx->stream, Z, ldv, (int)cols, n_pad, ipiv);
+    for (int ib = 0; ib < nb; ++ib) {
+        if (ib > 0) hipLaunchKernelGGL(k_lu_rect_update, dim3(ctiles), dim3(GEMM_THREADS), 0, ctx->stream, LU, ld, Z, ldv, ib, 0, ib * PB);
+        hipLaunchKernelGGL(k_lu_diag_solve<false>, dim3(cblocks), dim3(256), 0, ctx->stream, LU, ld, ib, Z, ldv, (int)cols);
+    }
+    for (int ib = nb - 1; ib >= 0; --ib) {
+        if (ib < nb - 1)
+            hipLaunchKernelGGL(k_lu_rect_update, dim3(ctiles), dim3(GEMM_THREADS), 0, ctx->stream, LU, ld, Z, ldv, ib, (ib + 1) * PB, n_pad);
+        hipLaunchKernelGGL(k_lu_diag_solve<true>, dim3(cblocks), dim3(256), 0, ctx->stream, LU, ld, ib, Z, ldv, (int)cols);
+    }
+    HIPCHK(hipGetLastError());
+    return GPBO_OK;
+}
+
 int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     if (!ctx->fitted) BADARG("posterior: no fitted model");
     if (ctx->xs_rows <= 0 || !ctx->Xs) BADARG("posterior: no candidates");
     ctx->m = ctx->xs_rows;       // a posterior uploaded with gpbo_set_posterior (any length) is replaced by the one of the resident candidates
     CHK(ensure_scratch(ctx));
+    if (ctx->variant == GPBO_VARIANT_KRIGING_LU && (!ctx->Zmat || ctx->z_chunk != ctx->chunk || ctx->z_npad != ctx->n_pad)) {
+        CHK(dev_alloc(ctx, &ctx->Zmat, (size_t)ctx->n_pad * ctx->chunk));
+        ctx->z_chunk = ctx->chunk;
+        ctx->z_npad = ctx->n_pad;
+    }
     const bool keep_v = (ctx->variant == GPBO_VARIANT_SINGLE && ctx->reserve > 0 && ctx->have_factor);   // also after the last append
     if (keep_v) {
         const int64_t rows = ctx->n + ctx->reserve_left;
@@ -581,10 +610,11 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                 int cg = std::min(nj, 128);   // column blocks per tile-order group
                 if (const char* e = getenv("GPBO_TRMM_COLGROUP")) cg = std::max(1, std::min(nj, atoi(e)));
                 // tile engine mode 2: priority raised over each MFMA burst, LDS fragments requested one k-substep ahead
-                if (ctx->variant == GPBO_VARIANT_KRIGING_LU)      // bufW is the full inverse: r^T Kinv r per candidate
-                    hipLaunchKernelGGL(k_gemm_dot, dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
-                                       (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
-                                       ctx->partial, nb, nj, cg);
+                if (ctx->variant == GPBO_VARIANT_KRIGING_LU) {    // bufW holds P K = L U: r^T K^-1 r per candidate through the factors
+                    CHK(launch_lu_solve(ctx, ctx->bufW, ctx->ipiv, ctx->Bmat, ctx->Zmat, (long)ctx->chunk, cols));
+                    hipLaunchKernelGGL(k_col_dot, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->Bmat,
+                                       (const double*)ctx->Zmat, (long)ctx->chunk, (int)ctx->n_pad, (int)cols, ctx->partial, nb);
+                }
                 else if (keep_v)
                     hipLaunchKernelGGL((k_trmm_sumsq<true, 2>), dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
@@ -918,7 +948,7 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     free_model(ctx);
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
                   ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
-                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres,     ctx->acq_pv,  ctx->acq_pi, ctx->bmax};
+                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres,     ctx->acq_pv,  ctx->acq_pi, ctx->bmax, ctx->Zmat};
     for (void* p : ps)
         if (p) hipFree(p);
     if (ctx->res_host) hipHostFree(ctx->res_host);
@@ -1417,6 +1447,7 @@ static int kriging_fit_impl(gpbo_ctx* ctx, const double* X, const double* y, int
     timing_begin(ctx);
     int info = 0;
     bool use_lu = false;
+    std::vector<double> lu_sol;
     {
         Scope tot(ctx, T_TOTAL);
         CHK(launch_kernel_matrix(ctx, ctx->bufA, nullptr, 0.0));
@@ -1431,8 +1462,7 @@ static int kriging_fit_impl(gpbo_ctx* ctx, const double* X, const double* y, int
                                (const double*)ctx->bufW, (long)n_pad, (int)n, (const double*)u_dev, x_dev, (int)n_pad);
         } else if (n_pad <= KRIGING_LU_MAX) {
             // K without jitter is not numerically positive definite: the reference's np.linalg.solve (LU with partial
-            // pivoting) still returns numbers there.  Same route: P K = L U, the explicit inverse into bufW, solves by
-            // multiplication with it.
+            // pivoting) still returns numbers there.  Same route: P K = L U in bufW, every solve by substitution with the factors.
             use_lu = true;
             ctx->variant = GPBO_VARIANT_KRIGING_LU;
             if (ctx->ipiv_cap < n_pad) {
@@ -1443,33 +1473,53 @@ static int kriging_fit_impl(gpbo_ctx* ctx, const double* X, const double* y, int
                 ctx->ipiv_cap = n_pad;
             }
             HIPCHK(hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
-            CHK(launch_kernel_matrix(ctx, ctx->bufA, nullptr, 0.0));
-            hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)(n_pad / 64), (unsigned)(n_pad / 4)), dim3(256), 0, ctx->stream, ctx->bufA, (int)n_pad);
+            double* LU = ctx->bufW;          // the matrix the sweep reads (and a multi-context handle hands over) is bufW on every route
+            CHK(launch_kernel_matrix(ctx, LU, nullptr, 0.0));
+            hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)(n_pad / 64), (unsigned)(n_pad / 4)), dim3(256), 0, ctx->stream, LU, (int)n_pad);
             const int nb = (int)ctx->nb;
             for (int pp = 0; pp < nb; ++pp) {
                 const int c0 = pp * PB;
-                hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), 0, ctx->stream, ctx->bufA, (long)n_pad, (int)n_pad, c0, ctx->ipiv, ctx->info_dev);
+                hipLaunchKernelGGL(k_lu_panel, dim3(1), dim3(1024), 0, ctx->stream, LU, (long)n_pad, (int)n_pad, c0, ctx->ipiv, ctx->info_dev);
                 if (nb > 1)
-                    hipLaunchKernelGGL(k_lu_swap_rows, dim3((unsigned)((n_pad - PB + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufA,
+                    hipLaunchKernelGGL(k_lu_swap_rows, dim3((unsigned)((n_pad - PB + 255) / 256)), dim3(256), 0, ctx->stream, LU,
                                        (long)n_pad, (int)n_pad, c0, (const int*)ctx->ipiv);
                 if (pp + 1 < nb) {
-                    hipLaunchKernelGGL(k_lu_trsm_u, dim3((unsigned)((n_pad - c0 - PB + 255) / 256)), dim3(256), 0, ctx->stream, ctx->bufA,
+                    hipLaunchKernelGGL(k_lu_trsm_u, dim3((unsigned)((n_pad - c0 - PB + 255) / 256)), dim3(256), 0, ctx->stream, LU,
                                        (long)n_pad, (int)n_pad, c0);
                     hipLaunchKernelGGL(k_lu_gemm_update, dim3((unsigned)(nb - pp - 1), (unsigned)(nb - pp - 1)), dim3(GEMM_THREADS), 0,
-                                       ctx->stream, ctx->bufA, (long)n_pad, pp);
+                                       ctx->stream, LU, (long)n_pad, pp);
                 }
             }
-            hipLaunchKernelGGL(k_lu_inverse_cols, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->bufA,
-                               (long)n_pad, (int)n_pad, (const int*)ctx->ipiv, ctx->bufW);
-            hipLaunchKernelGGL(k_full_gemv, dim3((unsigned)((n + 3) / 4), (unsigned)q), dim3(256), 0, ctx->stream, (const double*)ctx->bufW,
-                               (long)n_pad, (int)n, (const double*)rhs_dev, x_dev, (int)n_pad);
-            HIPCHK(hipGetLastError());
+            // the q right-hand sides as one k-major block of 128 columns (u_dev -> x_dev would be column-major: stage through
+            // two small matrices of the sweep's layout)
+            double *Rk = nullptr, *Zk = nullptr;
+            struct G2 {
+                double *&a, *&b;
+                ~G2() {
+                    if (a) hipFree(a);
+                    if (b) hipFree(b);
+                }
+            } g2{Rk, Zk};
+            HIPCHK(hipMalloc((void**)&Rk, (size_t)n_pad * TN * 8));
+            HIPCHK(hipMalloc((void**)&Zk, (size_t)n_pad * TN * 8));
+            std::vector<double> rk((size_t)n_pad * TN, 0.0);
+            for (int c = 0; c < q; ++c)
+                for (int64_t i = 0; i < n; ++i) rk[(size_t)i * TN + c] = rhs[(size_t)c * n_pad + i];
+            HIPCHK(hipMemcpyAsync(Rk, rk.data(), rk.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            CHK(launch_lu_solve(ctx, LU, ctx->ipiv, Rk, Zk, (long)TN, TN));
+            HIPCHK(hipMemcpyAsync(rk.data(), Zk, rk.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipMemcpyAsync(&info, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            lu_sol.assign((size_t)q * n_pad, 0.0);
+            for (int c = 0; c < q; ++c)
+                for (int64_t i = 0; i < n; ++i) lu_sol[(size_t)c * n_pad + i] = rk[(size_t)i * TN + c];
+            HIPCHK(hipGetLastError());
         }
     }
     HIPCHK(hipGetLastError());
     std::vector<double> sol((size_t)q * n_pad);
-    if (info == 0 || use_lu) HIPCHK(hipMemcpyAsync(sol.data(), x_dev, sol.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (use_lu) sol = lu_sol;
+    else if (info == 0) HIPCHK(hipMemcpyAsync(sol.data(), x_dev, sol.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     double ms[T_NCAT], cnt[T_NCAT];
     timing_collect(ctx, ms, cnt);

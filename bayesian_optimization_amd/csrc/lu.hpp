@@ -2,9 +2,12 @@
 // covariance matrix WITHOUT jitter (Gaussian_Process_Regression.ipynb:201-202, 232-233), which returns numbers for
 // matrices that are not numerically positive definite (the notebook's own 3-D cell: 800 grid points, cond 4e19), where a
 // Cholesky factorisation stops at a non-positive pivot.  When that happens the fit falls back to this path:
-//   P K = L U (blocked right-looking, panels of 128 columns, trailing update on the fp64 MFMA tile engine),
-//   Kinv = U^-1 L^-1 P explicitly (n^3, once per fit),
-//   per candidate r^T Kinv r on the tile engine (k_gemm_dot: the full product Kinv R with a fused column dot against R).
+//   P K = L U (blocked right-looking, panels of 128 columns, trailing update on the fp64 MFMA tile engine);
+//   every solve -- the trend's right-hand sides at the fit, the correlation vectors of a chunk of candidates in the sweep --
+//   is a pair of blocked triangular solves with those factors (block row by block row: one product on the tile engine with
+//   the rows already solved, one substitution inside the 128-row diagonal block), as the reference's LU solve does it.
+// No explicit inverse: at cond(K) > 1 / eps only the backward stability of the substitution keeps r^T K^-1 r and the
+// interpolant meaningful; a product with an explicitly formed inverse does not have it.
 // All matrices row-major n_pad x n_pad, identity padded, like everywhere else in the library.
 #pragma once
 #include "kernels.hpp"
@@ -127,48 +130,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_lu_gemm_update(double* __re
             for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = -acc[ta][tb][r];
 }
 
-// Column c of Kinv = U^-1 L^-1 P e_c, one thread per column: the exchanges move the 1 of e_c to row `pos`; forward
-// substitution with the unit lower factor from there on, backward substitution with U.  Each thread reads back only what it
-// wrote itself; for a fixed row the threads of a wave touch consecutive addresses.
-__global__ __launch_bounds__(256) void k_lu_inverse_cols(const double* __restrict__ LU, long ld, int n_pad, const int* __restrict__ ipiv,
-                                                         double* __restrict__ X) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_pad) return;
-    int pos = c;
-    for (int j = 0; j < n_pad; ++j) {
-        const int p = ipiv[j];
-        if (pos == j) pos = p;
-        else if (pos == p) pos = j;
-    }
-    for (int i = 0; i < n_pad; ++i) {
-        double s = (i == pos) ? 1.0 : 0.0;
-        if (i > pos) {
-            const double* Li = LU + (long)i * ld;
-            for (int k = pos; k < i; ++k) s -= Li[k] * X[(long)k * ld + c];
-        }
-        X[(long)i * ld + c] = s;
-    }
-    for (int i = n_pad - 1; i >= 0; --i) {
-        const double* Ui = LU + (long)i * ld;
-        double s = X[(long)i * ld + c];
-        for (int k = i + 1; k < n_pad; ++k) s -= Ui[k] * X[(long)k * ld + c];
-        X[(long)i * ld + c] = s / Ui[i];
-    }
-}
-
-// x = M v for q vectors stored column after column with pitch n_pad (M a full n x n matrix): wave per row.
-__global__ __launch_bounds__(256) void k_full_gemv(const double* __restrict__ M, long ld, int n, const double* __restrict__ v,
-                                                   double* __restrict__ x, int n_pad) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.y;
-    if (row >= n) return;
-    double s = 0.0;
-    for (int j = lane; j < n; j += 64) s += M[(long)row * ld + j] * v[(long)q * n_pad + j];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) x[(long)q * n_pad + row] = s;
-}
-
 // sum of log(diag) of a factor, rows < n.  One workgroup, fixed order.
 __global__ __launch_bounds__(256) void k_sumlog_diag(const double* __restrict__ L, long ld, int n, double* __restrict__ out) {
     __shared__ double r[256];
@@ -184,42 +145,82 @@ __global__ __launch_bounds__(256) void k_sumlog_diag(const double* __restrict__ 
     if (tid == 0) out[0] = r[0];
 }
 
-// The candidate sweep of the LU path: V = Kinv * Bmat over the full k range (Kinv is a full matrix), epilogue
-// partial[ib][j] = sum over the tile's 128 rows of V[row][j] * Bmat[row][j], so that sum_ib partial[ib][j] = r_j^T Kinv r_j.
-// Same tile engine, tile order and reduction shape as k_trmm_sumsq.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_dot(const double* __restrict__ Kinv, long ld, const double* __restrict__ Bmat,
-                                                            long ldb, double* __restrict__ partial, int nb, int nj, int cg) {
-    const int per = nb * cg;
-    const int grp = blockIdx.x / per, r0 = blockIdx.x % per;
-    const int cw = min(cg, nj - grp * cg);
-    const int ib = r0 / cw;
-    const int jb = grp * cg + r0 % cw;
+// ---- solves with the factors, for a k-major block of right-hand sides V[k][j] (row pitch ldv, `cols` columns)
+
+// V <- P V: the factorisation's row exchanges in order, one thread per column.
+__global__ __launch_bounds__(256) void k_lu_permute_rows(double* __restrict__ V, long ldv, int cols, int n_pad, const int* __restrict__ ipiv) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= cols) return;
+    for (int j = 0; j < n_pad; ++j) {
+        const int p = ipiv[j];
+        if (p != j) {
+            const double a = V[(long)j * ldv + x], b = V[(long)p * ldv + x];
+            V[(long)j * ldv + x] = b;
+            V[(long)p * ldv + x] = a;
+        }
+    }
+}
+
+// V[block row ib] -= LU[block row ib][k0 .. k1) * V[k0 .. k1): the part of a block row's substitution that involves rows
+// solved earlier, on the tile engine.  Grid: one workgroup per 128 columns of V.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_lu_rect_update(const double* __restrict__ LU, long ld, double* __restrict__ V, long ldv,
+                                                                  int ib, int k0, int k1) {
     __shared__ double lds[GEMM_LDS_DOUBLES];
+    const int jb = blockIdx.x;
+    const double* Arow = LU + (long)ib * PB * ld;                  // rows of the tile, k contiguous
+    const double* Bk = V + (long)jb * TN;                           // element (k, j) at Bk[k * ldv + j]
+    double* C = V + (long)ib * PB * ldv + (long)jb * TN;
     f64x4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_128<true, false, 2>(Kinv + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, nb * PB, acc, lds);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    double cs[4];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-        double s = 0.0;
+    for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
+        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                s += acc[ta][tb][r] * Bmat[(long)(ib * PB + acc_row(ta, r)) * ldb + (long)jb * TN + acc_col(tb)];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        cs[tb] = s;
+            for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)acc_row(ta, r) * ldv + acc_col(tb)];
+    gemm_tile_128<true, false, 1>(Arow, ld, Bk, ldv, k0, k1, acc, lds);
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ldv + acc_col(tb)] = -acc[ta][tb][r];
+}
+
+// Substitution inside diagonal block ib, in place, one thread per column of V.  UPPER = false: the unit lower triangle
+// (forward); UPPER = true: the upper triangle with its diagonal (backward).
+template <bool UPPER>
+__global__ __launch_bounds__(256) void k_lu_diag_solve(const double* __restrict__ LU, long ld, int ib, double* __restrict__ V, long ldv,
+                                                       int cols) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= cols) return;
+    const int r0 = ib * PB;
+    if (!UPPER) {
+        for (int i = 1; i < PB; ++i) {
+            const double* Li = LU + (long)(r0 + i) * ld + r0;
+            double s = V[(long)(r0 + i) * ldv + x];
+            for (int k = 0; k < i; ++k) s -= Li[k] * V[(long)(r0 + k) * ldv + x];
+            V[(long)(r0 + i) * ldv + x] = s;
+        }
+    } else {
+        for (int i = PB - 1; i >= 0; --i) {
+            const double* Ui = LU + (long)(r0 + i) * ld + r0;
+            double s = V[(long)(r0 + i) * ldv + x];
+            for (int k = i + 1; k < PB; ++k) s -= Ui[k] * V[(long)(r0 + k) * ldv + x];
+            V[(long)(r0 + i) * ldv + x] = s / Ui[i];
+        }
     }
-    double* red = lds;   // the tile engine ended on a barrier: LDS is free
-    if ((lane >> 4) == 0) {
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) red[wr * 128 + wc * 64 + tb * 16 + lane] = cs[tb];
-    }
-    __syncthreads();
-    if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
+}
+
+// partial[0][j] = sum_k R[k][j] Z[k][j] (= r_j^T K^-1 r_j once Z holds the solves), the other nb - 1 rows of partial zero:
+// the shape k_finalize sums.  One thread per column.
+__global__ __launch_bounds__(256) void k_col_dot(const double* __restrict__ R, const double* __restrict__ Z, long ldv, int n_pad, int cols,
+                                                 double* __restrict__ partial, int nb) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= cols) return;
+    double s = 0.0;
+    for (int k = 0; k < n_pad; ++k) s += R[(long)k * ldv + x] * Z[(long)k * ldv + x];
+    partial[x] = s;
+    for (int ib = 1; ib < nb; ++ib) partial[(long)ib * ldv + x] = 0.0;
 }
 
 }  // namespace gpbo

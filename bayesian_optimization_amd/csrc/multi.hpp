@@ -167,6 +167,16 @@ int multi_distribute(gpbo_multi* mg) {
         DCHK(hipMemcpyPeerAsync(c->alpha, c->device, src->alpha, src->device, (size_t)n_pad * 8, c->stream));
         DCHK(hipMemcpyPeerAsync(c->Xts, c->device, src->Xts, src->device, (size_t)MAX_D * n_pad * 8, c->stream));
         DCHK(hipMemcpyPeerAsync(c->params, c->device, src->params, src->device, PARAMS_DOUBLES * 8, c->stream));
+        if (src->variant == GPBO_VARIANT_KRIGING_LU) {      // the LU route of the trend flavour: bufW holds the factors, the row exchanges go with them
+            if (c->ipiv_cap < n_pad) {
+                if (c->ipiv) (void)hipFree(c->ipiv);
+                c->ipiv = nullptr;
+                c->ipiv_cap = 0;
+                DCHK(hipMalloc((void**)&c->ipiv, (size_t)n_pad * sizeof(int)));
+                c->ipiv_cap = n_pad;
+            }
+            DCHK(hipMemcpyPeerAsync(c->ipiv, c->device, src->ipiv, src->device, (size_t)n_pad * sizeof(int), c->stream));
+        }
         int64_t first, bytes;
         slice(r - 1, &first, &bytes);
         if (bytes > 0) DCHK(hipMemcpyPeerAsync(c->bufW + first, c->device, src->bufW + first, src->device, (size_t)bytes, c->stream));

@@ -178,6 +178,9 @@ def broadcast_model(gp, src: int = 0):
     dist.broadcast(hdr, src)
     hdr = hdr.cpu()
     n, d, kernel, variant = (int(hdr[i].item()) for i in range(4))
+    if variant == 4:
+        raise RuntimeError('broadcast_model: a trend model that fell back to LU (K not positive definite) carries row exchanges '
+                           'this hand-over does not move; use one process with MultiGP for it')
     sigmaY, y_max, n_pad = float(hdr[4].item()), float(hdr[5].item()), int(hdr[8].item())
     if rank != src:
         gp.state_alloc(n, d, kernel, variant, sigmaY, n_pad=n_pad)     # the sender's padding: it sizes every buffer below

@@ -173,6 +173,21 @@ def test_likelihood_settings_split_over_contexts(gp0):
             g.posterior()
         a, b = gp0.read(), mg.read()
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # ... and a K that is not positive definite without jitter (long length scale): the LU route's factors and row
+        # exchanges are handed over as well
+        xT3 = o.splitmix64_uniform(41, 300 * 3).reshape(300, 3) * 2 - 1
+        yT3 = np.sin(2 * xT3[:, 0]) + np.cos(xT3[:, 1]) + 6 * np.cos(xT3[:, 2])
+        b0, c0 = gp0.kriging_fit(xT3, yT3, 2.0, 0)
+        with pytest.raises(ValueError):
+            gp0.factor()                                   # the LU route ran: no Cholesky factor
+        b1, c1 = mg.kriging_fit(xT3, yT3, 2.0, 0)
+        assert np.array_equal(b0, b1) and c0 == c1
+        Xs3 = o.splitmix64_uniform(42, 700 * 3).reshape(700, 3) * 2 - 1
+        for g in (gp0, mg):
+            g.set_candidates(Xs3)
+            g.posterior()
+        a, b = gp0.read(), mg.read()
+        assert np.all(np.isfinite(a[0])) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     finally:
         mg.close()
 
