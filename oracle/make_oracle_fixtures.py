@@ -8,6 +8,8 @@ oracle.fit at a small size before it is trusted.  Takes ~10 minutes and ~20 GB o
 
     python oracle/make_oracle_fixtures.py fit                      # fit once; factor cached under /tmp; writes tests/golden/o1_cfg3_first512.npz
     python oracle/make_oracle_fixtures.py compare <sample.npz>     # oracle on the sample of scripts/full_cfg3.py -> profiles/r2_cfg3_full_parity.json
+    python oracle/make_oracle_fixtures.py grad                     # -logL + analytic gradient at n = 16384 for two settings of the
+                                                                   # 256-setting sweep -> tests/golden/o2_cfg5_grad.npz (~10 min, ~20 GB)
 """
 import json
 import math
@@ -164,9 +166,47 @@ def do_compare(sample_path):
     print(json.dumps(res, indent=1))
 
 
+def do_grad():
+    """The likelihood sweep's data (n = 16384, d = 8, RBF) and two of its 256 (length-scale multiplier, sigmaY) settings: -logL
+    (o.mlefcn, BayesOpt_v4.ipynb:154-165) and its analytic gradient (o.mle_grad, GP/BayesOpt_v3.m:392-417) from the CPU
+    restatement, called as they are.  A third, small problem is evaluated the same way and compared with central differences
+    of o.mlefcn first."""
+    Xs_, ys_ = o.splitmix64_uniform(9, 300 * 3).reshape(300, 3), None
+    ys_ = np.sin(3 * Xs_.sum(1))
+    th_ = np.array([0.4, 0.5, 0.6])
+    g_ = o.mle_grad(Xs_, ys_, th_, 0.1)
+    for t in range(3):
+        e = np.zeros(3)
+        e[t] = 1e-6
+        fd = (o.mlefcn(Xs_, ys_, th_ + e, 0.1) - o.mlefcn(Xs_, ys_, th_ - e, 0.1)) / 2e-6
+        assert abs(fd - g_[t]) <= 1e-6 * np.max(np.abs(g_)), (t, fd, g_[t])
+    n, d = 16384, 8
+    X = o.splitmix64_uniform(5, n * d).reshape(n, d)
+    u1, u2 = o.splitmix64_uniform(105, n), o.splitmix64_uniform(105 + 7919, n)
+    y = np.sin(3 * X.sum(1)) + 0.1 * (np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2))
+    mult = np.geomspace(0.25, 2.0, 16)
+    sigs = np.geomspace(1e-2, 1.0, 16)
+    picks = [(5, 8), (11, 4)]                                   # (multiplier index, sigma index) in the 16 x 16 grid
+    thetas = np.array([np.full(d, 0.5 * mult[i]) * (1 + 0.05 * np.arange(d)) for i, _ in picks])   # distinct scales per dimension
+    sg = np.array([sigs[j] for _, j in picks])
+    nll, grad = np.zeros(len(picks)), np.zeros((len(picks), d))
+    for b in range(len(picks)):
+        t0 = time.time()
+        nll[b] = o.mlefcn(X, y, thetas[b], float(sg[b]))
+        grad[b] = o.mle_grad(X, y, thetas[b], float(sg[b]))
+        print('setting %d: nll %.15g  |grad| %.6g  (%.0f s)' % (b, nll[b], np.max(np.abs(grad[b])), time.time() - t0), flush=True)
+    out = os.path.join(ROOT, 'tests', 'golden', 'o2_cfg5_grad.npz')
+    np.savez_compressed(out, n=np.array(n), d=np.array(d), seed_x=np.array(5), seed_noise=np.array(105), thetas=thetas, sigmas=sg,
+                        nll=nll, grad=grad, picks=np.array(picks), numpy_version=np.array(np.__version__),
+                        source=np.array('oracle/make_oracle_fixtures.py grad (CPU restatement: mlefcn + mle_grad as they are)'))
+    print('wrote', out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) >= 2 and sys.argv[1] == 'fit':
         do_fit()
+    elif len(sys.argv) >= 2 and sys.argv[1] == 'grad':
+        do_grad()
     elif len(sys.argv) >= 3 and sys.argv[1] == 'compare':
         do_compare(sys.argv[2])
     else:

@@ -31,13 +31,13 @@ def relmax(a, b):
 
 
 # Golden cases whose K + eps*I is so ill-conditioned (sigmaY = 0 -> jitter 1e-15*n, cond 4e11) that the reference's own
-# numbers are only defined to ~5e-7: the same LAPACK algorithm with another panel width moves theta1 (which scales every
-# variance) by 2-6e-7 and alpha by 0.6-2.3e-6, one-ulp changes of K's entries by as much, and the reference's theta1 is
-# 2.8e-7 from an extended-precision evaluation (scripts/illcond_noise_floor.py; tests/test_oracle_golden.py asserts it).
-# The NumPy restatement matches the reference to 1e-8 there only because it calls the same dpotrf on the same bits.
+# numbers are 1e-6 away from the exact posterior of the same inputs (fixture truth_g3_d4_n512_s0, 50-digit arithmetic:
+# reference theta1 3.0e-7, mean 9.9e-7, variance 3.4e-7 from the truth; the GPU 1.6e-8 / 2.7e-7 / 2.6e-8).  The principled
+# bound is test_badly_conditioned_models_are_no_further_from_the_truth_than_the_reference (GPU no further from the truth than
+# the reference is); the direct GPU-vs-reference comparison of the golden-vector test can then only be asked to hold to the
+# sum of the two distances, which is what the constants below are.
 ILL_CONDITIONED = {'g3_d4_n512_s0'}
-# bounds for those cases: about three times the spread of the CPU variants above
-ILL_TOL_MU, ILL_TOL_VAR, ILL_TOL_NLL = 5e-6, 2e-6, 2e-7
+ILL_TOL_MU, ILL_TOL_VAR, ILL_TOL_NLL = 3e-6, 1e-6, 2e-7
 
 # mean 1e-10 / variance 1e-8 (max-norm relative) are the stated targets; EI and alpha inherit the variance bound.
 TOL_MU, TOL_VAR = 1e-10, 1e-8

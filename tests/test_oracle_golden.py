@@ -287,3 +287,21 @@ def test_gpr_notebook_descent_path_against_the_restatement(name):
         wh, ch = o.gpr_descent(fun, dfun, float(alpha), float(beta), int(its), np.array([g['descent_w0'][r]]))
         assert np.max(np.abs(np.squeeze(np.array(wh)) - g['descent_w'][r])) <= 1e-9
         assert np.max(np.abs(np.array(ch) - g['descent_cost'][r]) / np.abs(g['descent_cost'][r])) <= 1e-7
+
+
+@pytest.mark.parametrize('name', ['g3_d4_n512_s0', 'g5_dup_train_s0'])
+def test_reference_distance_from_the_exact_posterior_at_bad_conditioning(name):
+    """truth_<name>: the exact posterior for the fixture's inputs (50-digit arithmetic).  Documents how far the reference's
+    own double-precision numbers are from it -- the yardstick of the GPU test for these cases -- and that the restatement
+    sits at the same distance."""
+    g, t = golden(name), golden('truth_' + name)
+    sub = t['idx']
+    mu_o, var_o, st = o.gprfcn_diag(g['xTest'][sub], g['xTrain'], g['yTrain'], g['theta'], float(g['sigmaY']))
+    ref_mu, ref_var = relmax(g['Mu'][sub], t['mu']), relmax(g['var'][sub], t['var'])
+    if name == 'g3_d4_n512_s0':
+        assert 1e-7 < ref_mu < 5e-6 and 5e-8 < ref_var < 2e-6            # cond 4e11: the reference is 1e-6 from the truth
+        assert abs(st['theta1'] - float(t['theta1'])) / float(t['theta1']) > 5e-8
+    else:
+        assert ref_mu < 1e-11 and ref_var < 1e-10                         # duplicated rows: mean and variance are fine ...
+        assert abs(float(g['nll']) - float(t['nll'])) / abs(float(t['nll'])) > 1e-6      # ... -logL is not (pivots of pure round-off)
+    assert relmax(mu_o, t['mu']) <= 2 * ref_mu + 1e-12 and relmax(var_o, t['var']) <= 2 * ref_var + 1e-12
