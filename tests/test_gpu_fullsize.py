@@ -105,3 +105,22 @@ def test_config3_model_against_the_cpu_oracle(gp0):
     assert idx == int(np.argmax(g['ei_local_incumbent']))
     _, alpha = gp0.factor(want_L=False)
     assert relmax(alpha[:64], g['alpha_head']) <= 1e-8
+
+
+def test_likelihood_and_gradient_at_n16384_against_the_cpu_oracle():
+    """Two of the 256 settings of the likelihood sweep (n = 16384, d = 8): -logL (mlefcn, BayesOpt_v4.ipynb:154-165) and its
+    analytic gradient (jacmlefun, GP/BayesOpt_v3.m:392-417) against the CPU restatement evaluated once at this size (fixture o2,
+    oracle/make_oracle_fixtures.py grad: one Cholesky, one inverse and one n^3 product per setting on the CPU).  The
+    restatement's gradient is pinned to the reference by finite differences of the reference's own mlefcn (fixture g6)."""
+    from bayesian_optimization_amd import GP, synth
+    g = golden('o2_cfg5_grad')
+    n, d = int(g['n']), int(g['d'])
+    X = synth.uniform(int(g['seed_x']), n * d).reshape(n, d)
+    y = np.sin(3 * X.sum(1)) + 0.1 * synth.normal(int(g['seed_noise']), n)
+    gp = GP(0)
+    nll, grad, stat = gp.lml_batch(X, y, g['thetas'], g['sigmas'], grad=True)
+    gp.close()
+    assert np.all(stat == 0)
+    for b in range(len(nll)):
+        assert abs(nll[b] - g['nll'][b]) <= 1e-10 * abs(g['nll'][b]), (b, nll[b], g['nll'][b])
+        assert np.max(np.abs(grad[b] - g['grad'][b])) <= 1e-8 * np.max(np.abs(g['grad'][b])), (b, grad[b], g['grad'][b])
