@@ -12,6 +12,8 @@ one-process-per-GPU form that torchrun launches.)
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -194,7 +196,10 @@ def broadcast_model(gp, src: int = 0):
         torch.cuda.synchronize(gp.device)
         for t in small:
             dist.broadcast(t, src)
-        scatter_allgather(W, src)
+        if os.environ.get('GPBO_BCAST', 'scatter') == 'root':      # one-root fan-out, for comparison runs
+            dist.broadcast(W, src)
+        else:
+            scatter_allgather(W, src)
         torch.cuda.synchronize(gp.device)
     else:                                            # gloo: stage through host memory
         for t in small:

@@ -16,8 +16,11 @@ if [ "${PMC:-0}" = "1" ]; then
   timeout -s KILL 200 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$O/fetch" -o f -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > /dev/null 2> "$O/f.err" || exit 1
   timeout -s KILL 200 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$O/write" -o w -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > /dev/null 2> "$O/w.err" || exit 1
   timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d "$O/sq" -o s -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > /dev/null 2> "$O/s.err" || exit 1
+  # L2 hit rate (TCC_HIT / (TCC_HIT + TCC_MISS)): tells how much of the operand re-reading stops at the XCD's L2; what
+  # misses shows up in FETCH_SIZE (L2 fills: Infinity Cache hits and HBM reads together -- no counter separates the two)
+  timeout -s KILL 200 rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d "$O/l2" -o l -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline "$@" > /dev/null 2> "$O/l.err" || echo "L2 pass failed (see l.err)"
   cd "$R" || exit 1
-  python3 scripts/summarize_pmc.py $(find "$O/fetch" "$O/write" "$O/sq" -name '*counter_collection.csv' | sort) > "$O/pmc_summary.txt"
+  python3 scripts/summarize_pmc.py $(find "$O/fetch" "$O/write" "$O/sq" "$O/l2" -name '*counter_collection.csv' | sort) > "$O/pmc_summary.txt"
 fi
 find "$O" -name '*.db' -delete; find "$O" -name '*counter_collection.csv' -size +20M -delete; find "$O/kt" -name '*kernel_trace.csv' -size +20M -delete
 head -8 "$O/kernel_stats.csv"
