@@ -117,15 +117,16 @@ def _ranks_seen(world):
 
 
 def _profiled_traffic(config, n, cand_per_launch):
-    """HBM bytes per launch of the dominant kernel from a committed PMC pass of the same workload (separate --pmc
-    runs, FETCH_SIZE doubled as the gfx950 counter needs).  Never measured in this run: reported beside a null
-    roofline.traffic, with the file it comes from."""
-    for name in ('r2_%s_traffic.json' % config, 'r1_%s_traffic.json' % config):
+    """Bytes per launch of the dominant kernel that crossed the L2 / fabric boundary, from a committed PMC pass of the same
+    workload (scripts/profile_bench.sh: separate --pmc runs, FETCH_SIZE doubled as the gfx950 counter needs).  Counters cannot
+    be read from inside this process: roofline.traffic carries the profiled figure, roofline.traffic_source says where from."""
+    for name in ('r3_%s_traffic.json' % config, 'r2_%s_traffic.json' % config, 'r1_%s_traffic.json' % config):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             tr = json.load(open(path))
             if tr['n_train'] == n and abs(cand_per_launch - tr['candidates_per_launch']) < 1:
-                return {'bytes_per_launch': tr['fetch_bytes_per_launch'] + tr['write_bytes_per_launch'], 'source': 'profiles/' + name}
+                return {'bytes_per_launch': tr['fetch_bytes_per_launch'] + tr['write_bytes_per_launch'], 'source': 'profiles/' + name,
+                        'algorithmic': tr.get('algorithmic_bytes_per_launch'), 'l2_hit_rate': tr.get('l2_hit_rate')}
         except Exception:
             continue
     return None
@@ -222,9 +223,11 @@ def sweep_block(a, config, gp, world, rank, backend, steps, warmup, with_cpu):
                    'candidates_per_gpu': m_local, 'candidates_total': m_total, 'n_train': n, 'd': cfg['d'],
                    'parallelism': 'candidate blocks per rank; all-reduce(max mu) + all-gather(argmax)'},
         'roofline': {'bound': 'mfma', 'kernel': 'k_trmm_sumsq', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
-                     'traffic_source': ('not measured in this run; %s holds %.4g bytes per launch for this workload'
-                                        % (prof['source'], prof['bytes_per_launch'])) if prof else 'not measured in this run',
+                     'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
+                     'traffic': prof['bytes_per_launch'] if prof else None,
+                     'traffic_source': ('%s: rocprofv3 PMC passes of this workload with this kernel (L2 fills + writes per launch, not '
+                                        'measured in this run; algorithmic %.4g bytes, L2 hit rate %s)'
+                                        % (prof['source'], prof['algorithmic'] or 0.0, prof['l2_hit_rate'])) if prof else 'not measured in this run',
                      'flops_per_launch': flops_per_launch, 'avg_launch_ms': avg_launch_s * 1e3, 'launches': trmm_launches},
         'phases_ms_per_step': {'posterior_total': post_ms / steps, 'ks_build': ks_ms / steps,
                                'trmm_sumsq': trmm_ms / steps, 'acquire': acq_ms / steps},
