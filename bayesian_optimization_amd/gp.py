@@ -604,11 +604,17 @@ def device_count():
 
 
 def make_gp(devices=None):
-    """A ``GP`` on one device or a ``MultiGP`` over several.  devices=None: every visible GPU, or the list in the environment
-    variable GPBO_DEVICES (comma-separated; an id may repeat, e.g. "0,0" = two contexts on GPU 0)."""
+    """A ``GP`` on one device or a ``MultiGP`` over several.  devices=None: the list in the environment variable
+    GPBO_DEVICES (comma-separated; an id may repeat, e.g. "0,0" = two contexts on GPU 0); else, under a one-process-per-GPU
+    launcher (LOCAL_RANK set), this rank's own GPU; else every visible GPU."""
     import os
     if devices is None:
         env = os.environ.get('GPBO_DEVICES')
-        devices = [int(v) for v in env.split(',')] if env else list(range(max(1, device_count())))
+        if env:
+            devices = [int(v) for v in env.split(',')]
+        elif os.environ.get('LOCAL_RANK') is not None:
+            devices = [int(os.environ['LOCAL_RANK'])]
+        else:
+            devices = list(range(max(1, device_count())))
     devices = [int(v) for v in np.atleast_1d(devices)]
     return GP(devices[0]) if len(devices) == 1 else MultiGP(devices)
