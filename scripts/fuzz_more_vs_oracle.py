@@ -191,8 +191,8 @@ for c in range(cases):
         e = float(np.max(diff)) / max(float(np.max(np.abs(ref[fin]))), 1e-300) if fin.any() else 0.0
         worst[name] = max(worst[name], e)
         nan_same = np.array_equal(np.isnan(vals), np.isnan(ref))
-        own = int(np.nanargmax(vals)) if np.isfinite(vals).any() else -1
-        ok = e <= 1e-12 and nan_same and (own < 0 or (idx == own and top == vals[own]))
+        own = int(np.argmax(vals))                      # np.argmax: the first NaN if there is one (0/0 where var = 0 and mu = incumbent)
+        ok = e <= 1e-12 and nan_same and idx == own and (top == vals[own] or (np.isnan(top) and np.isnan(vals[own])))
         if not ok:
             bad += 1
             print('MISMATCH acquisition', dict(m=m, acq=name, mode=mode, kappa=kappa), e, idx, own, flush=True)
