@@ -98,6 +98,15 @@ def _dist_setup(need_gpu=True):
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
         else:
             dist.init_process_group(backend)
+        if need_gpu:
+            # open every pairwise connection the model hand-over and the per-sweep exchanges use before anything is timed
+            # (the first point-to-point operation between two ranks sets the connection up: seconds, not microseconds)
+            from bayesian_optimization_amd import dist as gdist
+            w = torch.zeros(1 << 16, dtype=torch.float64, device='cuda')
+            gdist.scatter_allgather(w, 0)
+            dist.all_reduce(w[:1])
+            dist.broadcast(w[:8], 0)
+            torch.cuda.synchronize()
     return world, rank, dev, backend
 
 
