@@ -9,6 +9,7 @@ the tests measure how far the REFERENCE's double-precision answer is from the ma
 path to be no further away than a small multiple of that.
 
     python oracle/make_truth_fixtures.py [--out tests/golden] [--cases g3_d4_n512_s0,g5_dup_train_s0]
+    python oracle/make_truth_fixtures.py --grid      # -logL on the sigmaY = 0 likelihood grid of fixture g6 (mlefcn, :154-165)
 """
 import argparse
 import os
@@ -117,12 +118,47 @@ def truth_case(g, stride):
                 digits=np.array(getcontext().prec))
 
 
+def truth_nll(X, y, th, sY):
+    """-logL of mlefcn (BayesOpt_v4.ipynb:154-165) in extended precision."""
+    n = X.shape[0]
+    eps = D('1e-15') * n if sY == 0 else D(sY) * D(sY)
+    inv_th2 = [1 / (t * t) for t in dec(th)]
+    Xr = [dec(X[i]) for i in range(n)]
+    yv = dec(y)
+    A = [kernel_row(Xr[i], Xr, inv_th2) for i in range(n)]
+    for i in range(n):
+        A[i][i] += eps
+    L1 = cholesky(A)
+    a1 = solve_upper_t(L1, solve_lower(L1, yv))
+    theta1 = sum(p * q for p, q in zip(yv, a1)) / n
+    return D(n) / 2 * ((2 * D('3.14159265358979323846264338327950288419716939937510')).ln() + 1) + D(n) / 2 * theta1.ln() \
+        + sum(L1[i][i].ln() for i in range(n))
+
+
+def grid_truth(out):
+    g = np.load(os.path.join(out, 'g6_mle_grid.npz'))
+    X, y, th0 = np.asarray(g['xTrain'], dtype=np.float64), g['yTrain'], g['th0']
+    t0 = time.time()
+    T = np.empty((len(th0), len(th0)))
+    for i, a in enumerate(th0):
+        for j, b in enumerate(th0):
+            T[i, j] = float(truth_nll(X, y, np.array([a, b]), 0.0))
+        print('  row %d / %d  (%.0f s)' % (i + 1, len(th0), time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(out, 'truth_g6_sigma0.npz'), nll=T, th0=th0, digits=np.array(getcontext().prec))
+    err = np.abs(g['nll_sigma0'] - T) / np.abs(T)
+    print('  reference vs truth on the grid: median %.2e  max %.2e' % (np.median(err), err.max()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     here = os.path.dirname(os.path.abspath(__file__))
     ap.add_argument('--out', default=os.path.join(here, '..', 'tests', 'golden'))
     ap.add_argument('--cases', default='g3_d4_n512_s0,g5_dup_train_s0')
+    ap.add_argument('--grid', action='store_true')
     a = ap.parse_args()
+    if a.grid:
+        grid_truth(a.out)
+        return
     for name in a.cases.split(','):
         g = np.load(os.path.join(a.out, name + '.npz'))
         if int(g['raised_linalgerror']):

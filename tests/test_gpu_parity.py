@@ -241,6 +241,19 @@ def test_lml_batch_and_gradient(gp0):
             ok &= thetas.max(axis=1) <= 0.2
             assert ok.sum() >= 1
         assert np.max(np.abs(nll[ok] - ref[ok]) / np.abs(ref[ok])) <= (1e-8 if s == 0.0 else 1e-10)
+    # the whole sigmaY = 0 grid (256 settings, cond up to 1e13 and beyond) against 50-digit values of the same formula: the
+    # reference's own numbers are round-off there (median 1.3e-4, worst 1.2e-3 from the exact value), so what can be asked
+    # is that the library is no worse a sample of that noise (this call: the one-workgroup kernel, n = 94; the general path:
+    # test_sigma0_grid_general_path_against_the_exact_values) and exact where the matrix is well conditioned
+    T = golden('truth_g6_sigma0')['nll']
+    grid = np.array([[a, b] for a in th0 for b in th0])
+    nll, stat = gpl.lml_batch(X, y, grid, np.zeros(len(grid)))
+    assert np.all(stat == 0)
+    e_gpu = np.abs(nll.reshape(16, 16) - T) / np.abs(T)
+    e_ref = np.abs(g['nll_sigma0'] - T) / np.abs(T)
+    assert np.median(e_gpu) <= 2 * np.median(e_ref) and e_gpu.max() <= 2 * e_ref.max(), (np.median(e_gpu), e_gpu.max(), np.median(e_ref), e_ref.max())
+    corner = (np.maximum.outer(th0, th0) <= 0.2)
+    assert e_gpu[corner].max() <= 1e-8
     # gradient, well-conditioned settings
     pts = np.array([[0.1036165, 0.0995048], [0.3, 0.2], [0.8, 1.1], [0.1036165, 0.0995048]])
     sig = np.array([0.05, 0.05, 0.05, 0.0])
@@ -388,6 +401,24 @@ def test_small_n_fused_likelihood_equals_the_general_path(gp0):
         assert good.sum() >= B // 2
         assert np.max(np.abs(nll[good] - z['nll'][good]) / np.maximum(1.0, np.abs(nll[good]))) <= 1e-9
         assert np.max(np.abs(grad[good] - z['grad'][good])) <= 1e-7 * max(1.0, np.max(np.abs(grad[good])))
+
+
+def test_sigma0_grid_general_path_against_the_exact_values():
+    """The sigmaY = 0 likelihood grid of fixture g6 through the tile-engine path (GPBO_LML_SMALL=0, read from the environment:
+    child process): the same truth-anchored bound as for the one-workgroup kernel."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    g, T = golden('g6_mle_grid'), golden('truth_g6_sigma0')['nll']
+    out = os.path.join(ROOT, 'gpurun_out', 'grid_s0_general_test.npz')
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'grid_sigma0_dump.py'), out], env=dict(os.environ, GPBO_LML_SMALL='0'),
+                   check=True, timeout=120)
+    z = np.load(out)
+    assert np.all(z['stat'] == 0)
+    e_gpu = np.abs(z['nll'] - T) / np.abs(T)
+    e_ref = np.abs(g['nll_sigma0'] - T) / np.abs(T)
+    assert np.median(e_gpu) <= 2 * np.median(e_ref) and e_gpu.max() <= 2 * e_ref.max(), (np.median(e_gpu), e_gpu.max())
+    assert e_gpu[np.maximum.outer(g['th0'], g['th0']) <= 0.2].max() <= 1e-8
 
 
 @pytest.mark.parametrize('n', [60, 300])

@@ -305,3 +305,18 @@ def test_reference_distance_from_the_exact_posterior_at_bad_conditioning(name):
         assert ref_mu < 1e-11 and ref_var < 1e-10                         # duplicated rows: mean and variance are fine ...
         assert abs(float(g['nll']) - float(t['nll'])) / abs(float(t['nll'])) > 1e-6      # ... -logL is not (pivots of pure round-off)
     assert relmax(mu_o, t['mu']) <= 2 * ref_mu + 1e-12 and relmax(var_o, t['var']) <= 2 * ref_var + 1e-12
+
+
+def test_sigma0_likelihood_grid_reference_and_restatement_against_the_exact_values():
+    """truth_g6_sigma0: mlefcn on the 16 x 16 length-scale grid at sigmaY = 0 in 50-digit arithmetic.  Away from the short
+    length scales the reference's own values are round-off (median 1.3e-4, worst 1.2e-3 from the exact value); the
+    restatement, which calls the same LAPACK routines, is the same kind of sample."""
+    g, T = golden('g6_mle_grid'), golden('truth_g6_sigma0')['nll']
+    th0 = g['th0']
+    e_ref = np.abs(g['nll_sigma0'] - T) / np.abs(T)
+    assert 5e-5 < np.median(e_ref) < 5e-4 and 3e-4 < e_ref.max() < 5e-3
+    corner = np.maximum.outer(th0, th0) <= 0.2
+    assert e_ref[corner].max() <= 1e-9
+    mine = np.array([[o.mlefcn(g['xTrain'], g['yTrain'], np.array([a, b]), 0.0) for b in th0] for a in th0])
+    e_o = np.abs(mine - T) / np.abs(T)
+    assert np.median(e_o) <= 2 * np.median(e_ref) and e_o.max() <= 2 * e_ref.max()
