@@ -358,121 +358,6 @@ __device__ __forceinline__ void gemm_tile_64x64(const double* __restrict__ A, lo
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Tall form (experiment): one 512-thread workgroup (eight waves, 4 x 2, each 64 x 64) computes a 256 x 128 tile: two row
-// blocks of a lower-triangular A share every k-panel of B.  A row-major with k contiguous, B k-major.  A(i, k) = 0 for
-// k > tri_k0 + i, i = 0..255 (the tile's rows are rows tri_k0 + i of the triangular matrix): 16-row blocks that lie left
-// of a k-substep are skipped, so the upper four waves idle over the lower row block's last 128 k.
-// Per k-step a thread issues six 16-byte loads instead of eight.  LDS: 2 x (256 x 18 + 16 x 144) doubles = 110,592 B.
-constexpr int TALL_M = 256;
-constexpr int TALL_THREADS = 512;
-constexpr int TALL_A_DOUBLES = TALL_M * LDS_RK;              // 4608
-constexpr int TALL_BUF_DOUBLES = TALL_A_DOUBLES + TILE_DOUBLES;
-constexpr int TALL_LDS_DOUBLES = 2 * TALL_BUF_DOUBLES;       // 13,824 doubles
-
-struct StageTall {
-    f64x2 a[4];
-    f64x2 b[2];
-};
-
-__device__ __forceinline__ void load_tall(StageTall& s, const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
-                                          int k0, int tid) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int q = tid + TALL_THREADS * p;
-        s.a[p] = *reinterpret_cast<const f64x2*>(A + (long)(q >> 3) * lda + k0 + 2 * (q & 7));
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int q = tid + TALL_THREADS * p;
-        s.b[p] = *reinterpret_cast<const f64x2*>(B + (long)(k0 + (q >> 6)) * ldb + 2 * (q & 63));
-    }
-}
-
-__device__ __forceinline__ void store_tall(const StageTall& s, double* lds, int tid) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int q = tid + TALL_THREADS * p;
-        *reinterpret_cast<f64x2*>(lds + (q >> 3) * LDS_RK + 2 * (q & 7)) = s.a[p];
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int q = tid + TALL_THREADS * p;
-        *reinterpret_cast<f64x2*>(lds + TALL_A_DOUBLES + (q >> 6) * LDS_LD + 2 * (q & 63)) = s.b[p];
-    }
-}
-
-template <bool TRI>
-__device__ __forceinline__ void tall_k_step(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, int kn,
-                                            int k_rel, int row0, StageTall& st, const double* a_l, const double* b_l, double* nxt,
-                                            f64x4 (&acc)[4][4], int tid) {
-    load_tall(st, A, lda, B, ldb, kn, tid);
-    double af[2][4], bf[2][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        af[0][t] = a_l[t * 16 * LDS_RK];
-        bf[0][t] = b_l[t * 16];
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int kr = kk + 1, slot = (kk + 1) & 1;
-        if (kr < 4) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[slot][t] = a_l[kr * 4 + t * 16 * LDS_RK];
-                bf[slot][t] = b_l[kr * 4 * LDS_LD + t * 16];
-            }
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta) {
-            if (TRI && k_rel + kk * 4 > row0 + ta * 16 + 15) continue;
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
-                acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][ta], bf[kk & 1][tb], acc[ta][tb], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (kk == 0 && !TRI) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-        }
-        if (kk == 2) store_tall(st, nxt, tid);
-    }
-}
-
-// acc: this wave's 64 x 64 block; wave w: rows (w >> 1) * 64, columns (w & 1) * 64.  k runs over [0, k_end), the triangular
-// part starts at tri_k0 (k_end = tri_k0 + 256).
-__device__ __forceinline__ void gemm_tile_256x128(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
-                                                  int k_end, f64x4 (&acc)[4][4], double* lds, int tri_k0) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    StageTall st;
-    load_tall(st, A, lda, B, ldb, 0, tid);
-    store_tall(st, lds, tid);
-    __syncthreads();
-    int buf = 0;
-    const int a_off = (wr * 64 + (lane & 15)) * LDS_RK + (lane >> 4);
-    const int b_off = TALL_A_DOUBLES + wc * 64 + (lane & 15) + (lane >> 4) * LDS_LD;
-    int k0 = 0;
-    for (; k0 < tri_k0; k0 += TK) {
-        tall_k_step<false>(A, lda, B, ldb, k0 + TK, 0, 0, st, lds + buf * TALL_BUF_DOUBLES + a_off, lds + buf * TALL_BUF_DOUBLES + b_off,
-                           lds + (buf ^ 1) * TALL_BUF_DOUBLES, acc, tid);
-        __syncthreads();
-        buf ^= 1;
-    }
-    for (; k0 < k_end; k0 += TK) {
-        const int kn = (k0 + TK) < k_end ? k0 + TK : k0;
-        tall_k_step<true>(A, lda, B, ldb, kn, k0 - tri_k0, wr * 64, st, lds + buf * TALL_BUF_DOUBLES + a_off,
-                          lds + buf * TALL_BUF_DOUBLES + b_off, lds + (buf ^ 1) * TALL_BUF_DOUBLES, acc, tid);
-        __syncthreads();
-        buf ^= 1;
-    }
-}
-
 // Accumulator element acc[ta][tb][r] of this lane is output (row, col) of the tile:
 __device__ __forceinline__ int acc_row(int ta, int r) {
     const int tid = threadIdx.x;

@@ -619,15 +619,7 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                     hipLaunchKernelGGL((k_trmm_sumsq<true, 2>), dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, ctx->Vres, (long)ctx->m, (long)j0, (long)ctx->m, (int)ctx->n, cg);
-                else if (getenv("GPBO_TRMM_TALL") && nb % 2 == 0) {
-                    static bool attr_set = false;
-                    if (!attr_set) {
-                        HIPCHK(hipFuncSetAttribute((const void*)k_trmm_sumsq_tall, hipFuncAttributeMaxDynamicSharedMemorySize, TALL_LDS_DOUBLES * 8));
-                        attr_set = true;
-                    }
-                    hipLaunchKernelGGL(k_trmm_sumsq_tall, dim3((unsigned)(nb / 2 * nj)), dim3(TALL_THREADS), TALL_LDS_DOUBLES * 8, ctx->stream,
-                                       (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk, ctx->partial, nb, nj, cg);
-                } else
+                else
                     hipLaunchKernelGGL((k_trmm_sumsq<false, 2>), dim3((unsigned)(nb * nj)), dim3(GEMM_THREADS), 0, ctx->stream,
                                        (const double*)ctx->bufW, (long)ctx->n_pad, (const double*)ctx->Bmat, (long)ctx->chunk,
                                        ctx->partial, nb, nj, (double*)nullptr, 0L, (long)j0, (long)ctx->m, 0, cg);

@@ -1373,46 +1373,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __
     if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
 }
 
-// Experiment: the same product on 256 x 128 tiles (row blocks 2p and 2p + 1 of W against one column block), nb even.
-// Same sums in the same order as k_trmm_sumsq: bit-identical partial sums.
-__global__ __launch_bounds__(TALL_THREADS, 1) void k_trmm_sumsq_tall(const double* __restrict__ W, long ld, const double* __restrict__ Bmat,
-                                                                     long ldb, double* __restrict__ partial, int nb, int nj, int cg) {
-    const int np = nb / 2;
-    const int per = np * cg;
-    const int grp = blockIdx.x / per, r = blockIdx.x % per;
-    const int cw = min(cg, nj - grp * cg);
-    const int ib = 2 * (np - 1 - r / cw);
-    const int jb = grp * cg + r % cw;
-    extern __shared__ double lds_tall[];
-    f64x4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_256x128(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, (ib + 2) * PB, acc, lds_tall, ib * PB);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    double cs[4];
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-        double s = 0.0;
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s += acc[ta][tb][r] * acc[ta][tb][r];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        cs[tb] = s;
-    }
-    double* red = lds_tall;
-    if ((lane >> 4) == 0) {
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) red[wr * 128 + wc * 64 + tb * 16 + lane] = cs[tb];
-    }
-    __syncthreads();
-    if (tid < 256) {
-        const int half = tid >> 7, c = tid & 127;
-        partial[(long)(ib + half) * ldb + (long)jb * TN + c] = red[half * 256 + c] + red[half * 256 + 128 + c];
-    }
-}
-
 // Trend basis of the kriging flavour (polymat, Gaussian_Process_Regression.ipynb:113-140): columns for
 // C = 1..3 inputs and degree 0..3, in the reference's column order.  Returns f(x) . beta.
 __device__ __forceinline__ double trend_eval(const double* __restrict__ x, int C, int deg, const double* __restrict__ beta) {
