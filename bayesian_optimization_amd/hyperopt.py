@@ -10,6 +10,9 @@ Step rules: 'diminishing', 'backtrack' (the reference's own variant of the suffi
 :62-71; at most 200 shrinking rounds per iteration) and the constant step (any other string, as in the reference where 'normal' / 'standard' fall through to the else
 branch).  A start whose K stops being positive definite, or whose next iterate is not a set of finite non-zero length
 scales any more, is frozen with cost +inf (the reference would raise LinAlgError out of the whole multi-start loop).
+
+cg_optim / cg_optim_wrap restate the MATLAB scripts' version of the same descent (GP/BayesOpt_v3.m:457-514), which already
+uses the analytic gradient.
 """
 from __future__ import annotations
 
@@ -209,6 +212,92 @@ def hypopt_wrap(nruns, max_its, alpha, beta, normrule, steprule, xTrain, yTrain,
     iopt = int(np.argmin(ff))
     last = param_cont[iopt][-1] if np.isfinite(cost_cont[iopt][-1]) else param_cont[iopt][-2]
     return last
+
+
+def cg_optim(xTrain, yTrain, sigmaY, x0, alpha, beta, niter, normalize, device=None, kernel=0):
+    """The MATLAB scripts' descent on -logL (cg_optim, GP/BayesOpt_v3.m:457-484) with mle = mlefun (:367-390) and jmle =
+    jacmlefun (:392-417) -- the analytic gradient the library evaluates -- for every row of x0 (R, d) in lockstep: one
+    batched -logL + gradient call per iteration.  It differs from the notebook's conj_gradient_descent in four places,
+    all kept: the momentum term starts from the raw gradient at x0 (dtemp = jf_hist(1,:)), 'component' is normalize == 2
+    and 'full' normalize == 1, the stopping test is norm(step) <= 1e-9, and the histories are arrays of niter rows
+    allocated up front, so a start that stops early leaves ZERO rows behind its last iterate (x_hist(end,:) is then zero).
+    Returns (x_hist (R, niter, d), f_hist (R, niter), jf_hist (R, niter, d), exitflag (R,)).  MATLAB's chol raises where K
+    is not positive definite; so does this (numpy.linalg.LinAlgError, naming the start)."""
+    gp = _lml_gp(device)
+    X0 = np.atleast_2d(np.array(x0, dtype=np.float64))
+    R, d = X0.shape
+    niter = int(niter)
+    sig = np.full(R, float(sigmaY))
+    x_hist = np.zeros((R, niter, d))
+    f_hist = np.zeros((R, niter))
+    jf_hist = np.zeros((R, niter, d))
+    exitflag = np.zeros(R, dtype=int)
+
+    def evaluate(P, rows):
+        bad = rows[~np.all(np.isfinite(P[rows]) & (P[rows] != 0.0), axis=1)]
+        if len(bad):
+            raise np.linalg.LinAlgError('cg_optim: start %d left the set of finite non-zero length scales' % int(bad[0]))
+        nll, g, st = gp.lml_batch(xTrain, yTrain, P[rows], sig[rows], kernel=kernel, grad=True)
+        if np.any(st != 0):
+            raise np.linalg.LinAlgError('cg_optim: start %d: matrix is not positive definite' % int(rows[np.flatnonzero(st != 0)[0]]))
+        return nll, g
+
+    rows = np.arange(R)
+    x = X0.copy()
+    f, g = evaluate(x, rows)
+    x_hist[:, 0], f_hist[:, 0], jf_hist[:, 0] = x, f, g
+    dtemp = g.copy()
+    k = 1                                            # 0-based row being filled (MATLAB's k = 2)
+    while k < niter and len(rows):
+        jf_hist[rows, k] = g[rows]                   # jmle(x_hist(k-1,:)): the gradient of the previous evaluation
+        gr = g[rows]
+        if normalize == 1:
+            dd = (1 - beta) * dtemp[rows] + beta * gr / np.linalg.norm(gr, axis=1, keepdims=True)
+        elif normalize == 2:
+            dd = (1 - beta) * dtemp[rows] + beta * np.sign(gr) * np.sqrt(d)
+        else:
+            dd = (1 - beta) * dtemp[rows] + beta * gr
+        xn = x.copy()
+        xn[rows] = x[rows] - alpha * dd
+        fn, gn = evaluate(xn, rows)
+        x_hist[rows, k] = xn[rows]
+        f_hist[rows, k] = fn
+        dtemp[rows] = dd
+        stop = np.linalg.norm(xn[rows] - x[rows], axis=1) <= 1e-9
+        g[rows] = gn
+        x = xn
+        exitflag[rows[stop]] = 1
+        rows = rows[~stop]
+        k += 1
+    return x_hist, f_hist, jf_hist, exitflag
+
+
+def cg_optim_wrap(xTrain, yTrain, sigmaY, x0, lb, ub, alpha, beta, nruns, niter, normalize, starts=None, rng=None, device=None,
+                  kernel=0, mm=50):
+    """cg_optim_wrap (GP/BayesOpt_v3.m:486-514): nruns descents, the first from x0, the others from uniform random points
+    (in [lb, ub] when given, else in [0, 1)); the winner is the run with the lowest MEAN of its last mm + 1 = 51 costs
+    (f1_hist(niter-mm:end)), and what is returned is that run's LAST history row -- zero if it stopped early, as in MATLAB.
+    starts: optional (nruns - 1, d) array in place of the random draws (MATLAB's generator cannot be reproduced); rng: a
+    numpy Generator for them otherwise.  All runs advance together.  Returns (xopt (d,), fopt)."""
+    x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
+    d = x0.shape[0]
+    nruns, niter = int(nruns), int(niter)
+    if niter <= mm:
+        raise ValueError('cg_optim_wrap: niter must exceed mm = %d (f1_hist(niter-mm:end) starts at row niter - mm >= 1)' % mm)
+    if starts is None:
+        rng = np.random.default_rng() if rng is None else rng
+        u = rng.random((max(nruns - 1, 0), d))
+        no_box = (lb is None or np.size(lb) == 0) and (ub is None or np.size(ub) == 0)
+        starts = u if no_box else (np.asarray(ub, dtype=np.float64) - np.asarray(lb, dtype=np.float64)) * u + np.asarray(lb, dtype=np.float64)
+    starts = np.asarray(starts, dtype=np.float64).reshape(max(nruns - 1, 0), d)
+    x_hist, f_hist, _, _ = cg_optim(xTrain, yTrain, sigmaY, np.vstack([x0[None, :], starts]), alpha, beta, niter, normalize,
+                                    device=device, kernel=kernel)
+    score = f_hist[:, niter - mm - 1:].mean(axis=1)
+    best, fopt = 0, score[0]
+    for i in range(1, nruns):                         # "if fopt > f0": a later run wins only if strictly better
+        if fopt > score[i]:
+            best, fopt = i, score[i]
+    return x_hist[best, -1].copy(), float(fopt)
 
 
 def gpr_descent(xT, yT, deg, epsilon, alpha, beta, max_its, W0, fd_h=1e-6, device=None):

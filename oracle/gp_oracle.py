@@ -387,3 +387,42 @@ def splitmix64_uniform(seed, count, offset=0):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def cg_optim(X, y, sigmaY, x0, alpha, beta, niter, normalize, kernel=0):
+    """GP/BayesOpt_v3.m:457-484, one start, with mle = mlefcn and jmle = mle_grad (the restatements of mlefun :367-390 and
+    jacmlefun :392-417).  Histories are allocated with niter rows and keep their zeros behind an early stop, as in MATLAB."""
+    x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
+    d = x0.shape[0]
+    x_hist = np.zeros((niter, d)); x_hist[0] = x0                              # :460
+    f_hist = np.zeros(niter); f_hist[0] = mlefcn(X, y, x0, sigmaY, kernel)     # :461
+    jf_hist = np.zeros((niter, d)); jf_hist[0] = mle_grad(X, y, x0, sigmaY, kernel=kernel)   # :462
+    dtemp = jf_hist[0].copy()                                                  # :463
+    k, exitflag = 1, 0
+    while exitflag == 0 and k < niter:                                         # :466
+        jf_hist[k] = mle_grad(X, y, x_hist[k - 1], sigmaY, kernel=kernel)      # :467
+        if normalize == 1:
+            dd = (1 - beta) * dtemp + beta * jf_hist[k] / np.linalg.norm(jf_hist[k])          # :469
+        elif normalize == 2:
+            dd = (1 - beta) * dtemp + beta * np.sign(jf_hist[k]) * np.sqrt(d)                 # :471
+        else:
+            dd = (1 - beta) * dtemp + beta * jf_hist[k]                                       # :473
+        x_hist[k] = x_hist[k - 1] - alpha * dd                                 # :475
+        f_hist[k] = mlefcn(X, y, x_hist[k], sigmaY, kernel)                    # :476
+        dtemp = dd                                                             # :477
+        if np.linalg.norm(x_hist[k] - x_hist[k - 1]) <= 1e-9:                  # :478
+            exitflag = 1
+        k += 1
+    return x_hist, f_hist, jf_hist, exitflag
+
+
+def cg_optim_wrap(X, y, sigmaY, x0, starts, alpha, beta, niter, normalize, kernel=0, mm=50):
+    """GP/BayesOpt_v3.m:486-514 with the random restarts given (starts (nruns - 1, d))."""
+    xh, fh, _, _ = cg_optim(X, y, sigmaY, x0, alpha, beta, niter, normalize, kernel)
+    fopt, xopt = np.mean(fh[niter - mm - 1:]), xh[-1]                          # :492-493
+    for s0 in np.asarray(starts, dtype=np.float64).reshape(-1, len(xopt)):
+        xh, fh, _, _ = cg_optim(X, y, sigmaY, s0, alpha, beta, niter, normalize, kernel)
+        f0 = np.mean(fh[niter - mm - 1:])                                      # :506
+        if fopt > f0:                                                          # :508
+            xopt, fopt = xh[-1], f0
+    return xopt.copy(), float(fopt)

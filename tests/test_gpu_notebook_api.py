@@ -437,3 +437,32 @@ def test_gprfcn_loop_downloads_no_factor_unless_somebody_looks_at_it():
     assert L2.shape == (300, 300) and np.asarray(L2).shape == (300, 300) and (L2 @ np.ones(300)).shape == (300,)
     st = o.fit(X[:300], y[:300], theta, 0.05)
     assert relmax(np.asarray(L2), st['L2']) <= 1e-10 and relmax(np.asarray(a2)[:, 0], st['alpha']) <= 1e-9
+
+
+@pytest.mark.parametrize('normalize,alpha', [(2, 0.005), (1, 0.01), (0, 1e-4)])
+def test_matlab_cg_optim_on_the_device_likelihood(normalize, alpha):
+    """cg_optim / cg_optim_wrap of the MATLAB scripts (GP/BayesOpt_v3.m:457-514) on the device-evaluated -logL and analytic
+    gradient against the sequential CPU restatement: under the sign rule (normalize == 2) the iterates are identical as
+    long as no gradient component is within round-off of zero; under the other rules they drift by the 1e-8 of the
+    gradient times the step.  MATLAB cannot run here: parity with the reference is unpinned, the restatement follows the
+    script's text.  Two training sizes: the one-workgroup likelihood kernel (94 points) and the tile-engine path (300)."""
+    from bayesian_optimization_amd import hyperopt
+    g = golden('g9_descent_paths')
+    cases = [(g['xTrain'], g['yTrain'], float(g['sigmaY']), np.asarray(g['x0'], dtype=np.float64)[:3])]
+    rng = np.random.default_rng(11)
+    Xb = rng.random((300, 3))
+    cases.append((Xb, np.sin(3 * Xb.sum(1)) + 0.1 * rng.standard_normal(300), 0.1, rng.uniform(0.3, 0.9, (3, 3))))
+    niter = 56
+    for X, y, sY, x0 in cases:
+        xh, fh, jh, ex = hyperopt.cg_optim(X, y, sY, x0, alpha, 0.7, niter, normalize)
+        for r in range(len(x0)):
+            xo, fo, jo, eo = o.cg_optim(X, y, sY, x0[r], alpha, 0.7, niter, normalize)
+            assert ex[r] == eo
+            assert np.max(np.abs(xh[r] - xo)) <= (1e-12 if normalize == 2 else 1e-7)
+            assert np.max(np.abs(fh[r] - fo) / np.maximum(1.0, np.abs(fo))) <= 1e-8
+            assert np.max(np.abs(jh[r] - jo)) <= 1e-6 * max(1.0, np.max(np.abs(jo)))
+        got = hyperopt.cg_optim_wrap(X, y, sY, x0[0], None, None, alpha, 0.7, len(x0), niter, normalize, starts=x0[1:])
+        want = o.cg_optim_wrap(X, y, sY, x0[0], x0[1:], alpha, 0.7, niter, normalize)
+        assert np.max(np.abs(got[0] - want[0])) <= 1e-7 and abs(got[1] - want[1]) <= 1e-8 * max(1.0, abs(want[1]))
+    with pytest.raises(np.linalg.LinAlgError):
+        hyperopt.cg_optim(cases[0][0], cases[0][1], 0.0, np.array([[0.2, np.nan]]), 0.01, 1.0, 5, 2)

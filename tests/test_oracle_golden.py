@@ -320,3 +320,41 @@ def test_sigma0_likelihood_grid_reference_and_restatement_against_the_exact_valu
     mine = np.array([[o.mlefcn(g['xTrain'], g['yTrain'], np.array([a, b]), 0.0) for b in th0] for a in th0])
     e_o = np.abs(mine - T) / np.abs(T)
     assert np.median(e_o) <= 2 * np.median(e_ref) and e_o.max() <= 2 * e_ref.max()
+
+
+def _cg_problem():
+    g = golden('g9_descent_paths')
+    return g['xTrain'], g['yTrain'], float(g['sigmaY']), np.asarray(g['x0'], dtype=np.float64)
+
+
+@pytest.mark.parametrize('normalize', [0, 1, 2])
+def test_matlab_cg_optim_lockstep_equals_the_sequential_restatement(monkeypatch, normalize):
+    """cg_optim of the MATLAB scripts (GP/BayesOpt_v3.m:457-484): the lockstep version in hyperopt.py, run on the CPU
+    restatement of the likelihood, against the line-by-line sequential restatement in the oracle -- same iterates, same
+    costs, same gradients, bit for bit (host logic only).  MATLAB cannot run here: parity with the reference is unpinned,
+    the restatement follows the script's text."""
+    from bayesian_optimization_amd import hyperopt
+    monkeypatch.setitem(hyperopt._ctx, None, _OracleLml())
+    X, y, sY, x0 = _cg_problem()
+    alpha = {0: 1e-4, 1: 0.01, 2: 0.005}[normalize]
+    xh, fh, jh, ex = hyperopt.cg_optim(X, y, sY, x0, alpha, 0.7, 25, normalize)
+    for r in range(len(x0)):
+        xo, fo, jo, eo = o.cg_optim(X, y, sY, x0[r], alpha, 0.7, 25, normalize)
+        assert np.array_equal(xh[r], xo) and np.array_equal(fh[r], fo) and np.array_equal(jh[r], jo) and ex[r] == eo
+    assert np.all(fh[:, -1] < fh[:, 0])                       # it is a descent
+
+
+def test_matlab_cg_optim_early_stop_leaves_zero_rows_and_wrap_picks_by_mean_of_the_tail(monkeypatch):
+    """A start that stops early (step <= 1e-9) leaves zero rows behind its last iterate (the histories are preallocated,
+    :460-462), so the wrapper's x1_hist(end,:) is zero for it and its tail mean counts the zeros (:492-493, :506-511)."""
+    from bayesian_optimization_amd import hyperopt
+    monkeypatch.setitem(hyperopt._ctx, None, _OracleLml())
+    X, y, sY, x0 = _cg_problem()
+    xh, fh, jh, ex = hyperopt.cg_optim(X, y, sY, x0[:2], 1e-13, 1.0, 6, 2)
+    assert list(ex) == [1, 1] and np.all(xh[:, 2:] == 0) and np.all(fh[:, 2:] == 0) and np.all(xh[:, 1] != 0)
+    niter = 60
+    got = hyperopt.cg_optim_wrap(X, y, sY, x0[0], None, None, 0.004, 0.8, len(x0), niter, 2, starts=x0[1:])
+    want = o.cg_optim_wrap(X, y, sY, x0[0], x0[1:], 0.004, 0.8, niter, 2)
+    assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+    with pytest.raises(ValueError):
+        hyperopt.cg_optim_wrap(X, y, sY, x0[0], None, None, 0.004, 0.8, 2, 50, 2, starts=x0[1:2])
