@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -53,3 +55,22 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith(('.py', '.hip', '.hpp', '.h')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in txt.lower().replace('the oracle check', ''), os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c99_and_the_c_caller_links():
+    """include/gpbo.h must be usable from C (no C++ constructs): the header compiles under gcc -std=c99 -pedantic, and the
+    C99 caller of the GPU tests builds and links against the library (no GPU call is made here)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    src = os.path.join(ROOT, 'tests', 'c_caller', 'bo_body.c')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), src],
+                   check=True, timeout=120)
+    import __graft_entry__ as ge
+    ge.build()
+    caller = os.path.join(ROOT, 'tests', 'c_caller', 'bo_body')
+    assert os.path.exists(caller)
+    und = subprocess.run(['nm', '-D', '--undefined-only', caller], check=True, stdout=subprocess.PIPE, timeout=60).stdout.decode()
+    for sym in ('gpbo_create', 'gpbo_fit', 'gpbo_predict_ei', 'gpbo_lml_batch', 'gpbo_destroy', 'gpbo_last_error'):
+        assert sym in und
