@@ -24,10 +24,10 @@ class Timings(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
         'fit_total_ms', 'kbuild_ms', 'chol_ms', 'chol_count', 'trsv_ms', 'inverse_ms',
         'posterior_total_ms', 'ksbuild_ms', 'trmm_ms', 'trmm_launches', 'finalize_ms',
-        'acquire_ms', 'trmm_flops', 'append_total_ms', 'append_sweep_ms')] + [('reserved', C.c_double * 1)]
+        'acquire_ms', 'trmm_flops', 'append_total_ms', 'append_sweep_ms', 'append_route')]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class StateDesc(C.Structure):
@@ -55,6 +55,7 @@ SIGNATURES = {
     'gpbo_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, _dp, C.c_double, C.c_int32, C.c_int32, _dp, _dp]),
     'gpbo_set_candidates': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     'gpbo_set_candidates_uniform': (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64]),
+    'gpbo_set_candidates_lattice': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32]),
     'gpbo_posterior': (C.c_int, [C.c_void_p, _dp]),
     'gpbo_acquire': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, _i64p, _dp]),
     'gpbo_first_at_least': (C.c_int, [C.c_void_p, C.c_double, _i64p]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     'gpbo_multi_kriging_fit': (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, C.c_int32, C.c_double, C.c_int32, _dp, _i32p, _dp]),
     'gpbo_multi_set_candidates': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     'gpbo_multi_set_candidates_uniform': (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64]),
+    'gpbo_multi_set_candidates_lattice': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32]),
     'gpbo_multi_posterior': (C.c_int, [C.c_void_p, _dp]),
     'gpbo_multi_acquire': (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, _i64p, _dp]),
     'gpbo_multi_first_at_least': (C.c_int, [C.c_void_p, C.c_double, _i64p]),

@@ -17,6 +17,7 @@
 #include "../../include/gpbo.h"
 #include "kernels.hpp"
 #include "lu.hpp"
+#include "lattice.hpp"
 
 #define GPBO_VARIANT_KRIGING 2      /* trend GP of Gaussian_Process_Regression.ipynb:197-234 (internal tag) */
 #define GPBO_VARIANT_KRIGING_LU 4   /* the same model solved through LU with partial pivoting: bufW holds P K = L U, ipiv the row exchanges */
@@ -62,6 +63,17 @@ struct gpbo_ctx {
     int64_t v_cap_rows = 0, v_cap_m = 0;
     bool inc_valid = false;     // Vres/sres describe the current model and candidates
     std::vector<double> h_xnew;
+
+    // candidates given as a lattice (gpbo_set_candidates_lattice): with the RBF kernel an append takes the new row of V
+    // as a matrix product of per-axis factors (lattice.hpp) and V is not kept
+    bool lattice = false;       // the resident candidates are the full lattice of lat (lexicographic order)
+    bool inc_lattice = false;   // the current incremental state (sres, latE, latB) is the lattice route's
+    LatticeDesc lat{};
+    double *lat_axes = nullptr, *latA = nullptr, *latB = nullptr, *latE = nullptr, *lat_bmax = nullptr;
+    int64_t lat_axes_cap = 0, lat_kcap = 0, lat_ppad = 0, lat_qpad = 0, lat_smax = 0, lat_a_cap = 0, lat_b_cap = 0, lat_e_cap = 0,
+            lat_bmax_cap = 0, sres_cap = 0;
+    long sweep_parts = 0;       // per-workgroup max(mu) partials the last append left in its first-stage buffer
+    double* sweep_part_buf = nullptr;
 
     // workspace of the one-workgroup likelihood kernel (n <= 128), kept between calls
     double* sm_buf = nullptr;
@@ -550,6 +562,49 @@ int launch_lu_solve(gpbo_ctx* ctx, const double* LU, const int* ipiv, const doub
     return GPBO_OK;
 }
 
+// GPBO_LATTICE=0 keeps the streaming route (resident V) on lattice candidates too: same-machine comparison of the two.
+bool lattice_route_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("GPBO_LATTICE");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
+// Buffers of the lattice route for the fitted model's capacity: A (P_pad x kcap, row-major), B (kcap x Q_pad, k-major), the
+// factor table of the prefix axes, the per-tile max(mu) partials.  Rows and columns beyond what has been written stay zero.
+int lattice_ensure(gpbo_ctx* ctx) {
+    const int64_t kcap = round_up(ctx->n + ctx->reserve_left + 1, TK);
+    const int64_t ppad = round_up(ctx->lat.P, QUARTER_M), qpad = round_up(ctx->lat.Q, QUARTER_M);
+    int64_t smax = 1;
+    for (int t = 0; t < ctx->lat.d; ++t) smax = std::max<int64_t>(smax, ctx->lat.size[t]);
+    const int64_t a_need = ppad * kcap, b_need = kcap * qpad, e_need = (int64_t)std::max(ctx->lat.split, 1) * smax * kcap;
+    const int64_t tiles = (ppad / QUARTER_M) * (qpad / QUARTER_M);
+    if (a_need > ctx->lat_a_cap) {
+        CHK(dev_alloc(ctx, &ctx->latA, (size_t)a_need));
+        ctx->lat_a_cap = a_need;
+    }
+    if (b_need > ctx->lat_b_cap) {
+        CHK(dev_alloc(ctx, &ctx->latB, (size_t)b_need));
+        ctx->lat_b_cap = b_need;
+    }
+    if (e_need > ctx->lat_e_cap) {
+        CHK(dev_alloc(ctx, &ctx->latE, (size_t)e_need));
+        ctx->lat_e_cap = e_need;
+    }
+    if (tiles > ctx->lat_bmax_cap) {
+        CHK(dev_alloc(ctx, &ctx->lat_bmax, (size_t)tiles));
+        ctx->lat_bmax_cap = tiles;
+    }
+    HIPCHK(hipMemsetAsync(ctx->latA, 0, (size_t)a_need * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->latB, 0, (size_t)b_need * sizeof(double), ctx->stream));
+    ctx->lat_kcap = kcap;
+    ctx->lat_ppad = ppad;
+    ctx->lat_qpad = qpad;
+    ctx->lat_smax = smax;
+    return GPBO_OK;
+}
+
 int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     if (!ctx->fitted) BADARG("posterior: no fitted model");
     if (ctx->xs_rows <= 0 || !ctx->Xs) BADARG("posterior: no candidates");
@@ -560,16 +615,23 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
         ctx->z_chunk = ctx->chunk;
         ctx->z_npad = ctx->n_pad;
     }
-    const bool keep_v = (ctx->variant == GPBO_VARIANT_SINGLE && ctx->reserve > 0 && ctx->have_factor);   // also after the last append
+    const bool keep_inc = (ctx->variant == GPBO_VARIANT_SINGLE && ctx->reserve > 0 && ctx->have_factor);   // also after the last append
+    // lattice candidates + RBF: appends take the new row of V from a product of per-axis factors, V itself is not kept
+    const bool lat = keep_inc && ctx->lattice && ctx->kernel == GPBO_KERNEL_RBF && lattice_route_enabled();
+    const bool keep_v = keep_inc && !lat;
     if (keep_v) {
         const int64_t rows = ctx->n + ctx->reserve_left;
         if (rows > ctx->v_cap_rows || ctx->m > ctx->v_cap_m || !ctx->Vres) {
             CHK(dev_alloc(ctx, &ctx->Vres, (size_t)rows * ctx->m));
-            CHK(dev_alloc(ctx, &ctx->sres, (size_t)ctx->m));
             ctx->v_cap_rows = rows;
             ctx->v_cap_m = ctx->m;
         }
     }
+    if (keep_inc && (ctx->m > ctx->sres_cap || !ctx->sres)) {
+        CHK(dev_alloc(ctx, &ctx->sres, (size_t)ctx->m));
+        ctx->sres_cap = ctx->m;
+    }
+    if (lat) CHK(lattice_ensure(ctx));
     ctx->inc_valid = false;
     timing_begin(ctx);
     const int nkc = (int)((ctx->n_pad + ctx->kc - 1) / ctx->kc);
@@ -630,13 +692,18 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
                 hipLaunchKernelGGL(k_finalize, dim3((unsigned)(cols / 256)), dim3(256), 0, ctx->stream,
                                    (const double*)ctx->partial, (const double*)ctx->mupart, (long)ctx->chunk, nb, nkc,
                                    (const double*)ctx->params, ctx->mu, ctx->var, (long)j0, (long)ctx->m,
-                                   keep_v ? ctx->sres : (double*)nullptr, (const double*)ctx->Xs, ctx->d);
+                                   keep_inc ? ctx->sres : (double*)nullptr, (const double*)ctx->Xs, ctx->d);
             }
         }
         {
             Scope s(ctx, T_FIN);
             CHK(reduce_max(ctx, ctx->mu, ctx->m, ctx->inc_dev + 1));
         }
+        if (lat)      // factor tables and B for the training points of the fit; every append adds one row
+            hipLaunchKernelGGL(k_lattice_rows, dim3((unsigned)((std::max<int64_t>(ctx->lat_qpad, ctx->lat.split * ctx->lat_smax) + 255) / 256), (unsigned)ctx->n),
+                               dim3(256), 0, ctx->stream, ctx->lat, (const double*)ctx->lat_axes, (const double*)ctx->params,
+                               (const double*)ctx->Xts, (long)ctx->n_pad, 0, ctx->latE, (int)ctx->lat_kcap, (int)ctx->lat_smax, ctx->latB,
+                               (long)ctx->lat_qpad);
     }
     HIPCHK(hipGetLastError());
     double mu_max = 0;
@@ -652,7 +719,8 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     ctx->tm.trmm_flops = (double)ctx->n * (double)ctx->n * (double)ctx->m;
     ctx->have_posterior = true;
     ctx->have_acq = false;
-    ctx->inc_valid = keep_v;
+    ctx->inc_valid = keep_inc;
+    ctx->inc_lattice = lat;
     if (mu_max_out) *mu_max_out = mu_max;
     return GPBO_OK;
 }
@@ -683,7 +751,8 @@ int append_check(gpbo_ctx* ctx, const double* x_new) {
     if (ctx->variant != GPBO_VARIANT_SINGLE) BADARG("append: only the single-factor variant can be updated incrementally");
     if (!x_new) BADARG("append: null x_new");
     if (!ctx->inc_valid || ctx->m != ctx->xs_rows) BADARG("append: call gpbo_reserve_appends, gpbo_fit, gpbo_set_candidates and gpbo_posterior first");
-    if (ctx->reserve_left <= 0 || ctx->n + 1 > ctx->n_pad || ctx->n + 1 > ctx->v_cap_rows) BADARG("append: reserved rows exhausted (gpbo_reserve_appends)");
+    if (ctx->reserve_left <= 0 || ctx->n + 1 > ctx->n_pad || ctx->n + 1 > (ctx->inc_lattice ? ctx->lat_kcap : ctx->v_cap_rows))
+        BADARG("append: reserved rows exhausted (gpbo_reserve_appends)");
     return GPBO_OK;
 }
 
@@ -701,7 +770,26 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new, bool defer_
                        (const double*)ctx->kvec, ctx->lvec);
     hipLaunchKernelGGL(k_append_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->lvec, ctx->zfw, ctx->yv, n,
                        y_new, ctx->eps, ctx->scal, ctx->params, ctx->bufL, ctx->bufW, ld, ctx->info_dev);
-    {
+    if (ctx->inc_lattice) {
+        Scope sw(ctx, T_SWEEP);
+        const int kpad = (int)round_up(n + 1, TK);
+        const int tiles_q = (int)(ctx->lat_qpad / QUARTER_M);
+        const long tiles = (long)(ctx->lat_ppad / QUARTER_M) * tiles_q;
+        hipLaunchKernelGGL(k_append_wrow, dim3((unsigned)((n + 1 + 31) / 32)), dim3(256), 0, ctx->stream, ctx->bufW, ld, n,
+                           (const double*)ctx->lvec, (const double*)ctx->scal, (const double*)ctx->zfw, ctx->alpha1, ctx->alpha);
+        hipLaunchKernelGGL(k_lattice_rows, dim3((unsigned)((std::max<int64_t>(ctx->lat_qpad, ctx->lat.split * ctx->lat_smax) + 255) / 256), 1u),
+                           dim3(256), 0, ctx->stream, ctx->lat, (const double*)ctx->lat_axes, (const double*)ctx->params,
+                           (const double*)ctx->Xts, (long)ctx->n_pad, n, ctx->latE, (int)ctx->lat_kcap, (int)ctx->lat_smax, ctx->latB,
+                           (long)ctx->lat_qpad);
+        hipLaunchKernelGGL(k_lattice_A, dim3((unsigned)((ctx->lat.P * kpad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->lat,
+                           (const double*)ctx->latE, (int)ctx->lat_kcap, (int)ctx->lat_smax, (const double*)(ctx->bufW + (long)n * ld), n,
+                           ctx->latA, (long)ctx->lat_kcap, kpad);
+        hipLaunchKernelGGL(k_lattice_gemm_update, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, ctx->stream, (const double*)ctx->latA,
+                           (long)ctx->lat_kcap, (const double*)ctx->latB, (long)ctx->lat_qpad, kpad, ctx->lat.P, ctx->lat.Q, tiles_q,
+                           (const double*)ctx->scal, (const double*)ctx->params, ctx->sres, ctx->mu, ctx->var, ctx->lat_bmax);
+        ctx->sweep_parts = tiles;
+        ctx->sweep_part_buf = ctx->lat_bmax;
+    } else {
         Scope sw(ctx, T_SWEEP);
         switch (ctx->d) {
             case 1: launch_sweep_t<1>(ctx); break;
@@ -714,12 +802,14 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new, bool defer_
             case 8: launch_sweep_t<8>(ctx); break;
             default: launch_sweep_t<0>(ctx); break;
         }
+        ctx->sweep_parts = (ctx->m % 2 == 0) ? (ctx->m / 2 + 255) / 256 : (ctx->m + 255) / 256;
+        ctx->sweep_part_buf = ctx->bmax;
     }
     // stages 2 and 3 of max(mu) over the sweep's per-workgroup maxima; the last one also fills the incumbent slot
     // (used when the acquisition that follows takes max(mu) as its incumbent)
-    const long sweep_blocks = (ctx->m % 2 == 0) ? (ctx->m / 2 + 255) / 256 : (ctx->m + 255) / 256;
+    const long sweep_blocks = ctx->sweep_parts;
     const int b2 = (int)std::min<long>(256, (sweep_blocks + 255) / 256);
-    hipLaunchKernelGGL(k_max_stage, dim3(b2), dim3(256), 0, ctx->stream, (const double*)ctx->bmax, sweep_blocks, ctx->red_v, (double*)nullptr);
+    hipLaunchKernelGGL(k_max_stage, dim3(b2), dim3(256), 0, ctx->stream, (const double*)ctx->sweep_part_buf, sweep_blocks, ctx->red_v, (double*)nullptr);
     // (deferred: the acquisition kernel that follows takes the maximum of the b2 second-stage results itself)
     if (!defer_last_max)
         hipLaunchKernelGGL(k_max_stage, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->red_v, (long)b2, ctx->inc_dev + 1, ctx->inc_dev);
@@ -736,8 +826,7 @@ int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incum
     if (mode == GPBO_INCUMBENT_MAX_MU && inc_ready) {
         // the append sweep that was just enqueued left the second-stage maxima of mu in red_v: the acquisition kernel reduces
         // them itself and fills the incumbent and max(mu) slots (the third stage has no launch of its own)
-        const long sweep_blocks = (ctx->m % 2 == 0) ? (ctx->m / 2 + 255) / 256 : (ctx->m + 255) / 256;
-        n_parts = (int)std::min<long>(256, (sweep_blocks + 255) / 256);
+        n_parts = (int)std::min<long>(256, (ctx->sweep_parts + 255) / 256);
         inc_parts = ctx->red_v;
     } else if (mode == GPBO_INCUMBENT_MAX_MU)
         hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, ctx->inc_dev, (const double*)(ctx->inc_dev + 1));
@@ -795,6 +884,7 @@ int append_finish(gpbo_ctx* ctx, const StepResult& r, double* mu_max_out) {
     timing_collect(ctx, ms, cnt);
     ctx->tm.append_total_ms = ms[T_TOTAL];
     ctx->tm.append_sweep_ms = ms[T_SWEEP];
+    ctx->tm.append_route = ctx->inc_lattice ? 1.0 : 0.0;
     ctx->tm.acquire_ms = ms[T_ACQ];
     if (r.info != 0) {
         ctx->info = r.info;
@@ -885,6 +975,7 @@ int reserve_candidates(gpbo_ctx* ctx, int64_t m) {
     ctx->have_posterior = false;
     ctx->have_acq = false;
     ctx->inc_valid = false;
+    ctx->lattice = false;        // (gpbo_set_candidates_lattice sets it again)
     return GPBO_OK;
 }
 
@@ -948,7 +1039,8 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     free_model(ctx);
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
                   ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
-                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres,     ctx->acq_pv,  ctx->acq_pi, ctx->bmax, ctx->Zmat};
+                  ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres,     ctx->acq_pv,  ctx->acq_pi, ctx->bmax, ctx->Zmat,
+                  ctx->lat_axes, ctx->latA,   ctx->latB,  ctx->latE,     ctx->lat_bmax};
     for (void* p : ps)
         if (p) hipFree(p);
     if (ctx->res_host) hipHostFree(ctx->res_host);
@@ -1100,6 +1192,45 @@ int gpbo_set_candidates_uniform(gpbo_ctx* ctx, uint64_t seed, int64_t row_offset
                        (unsigned long long)seed, (unsigned long long)row_offset * (unsigned long long)ctx->d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GPBO_OK;
+}
+
+int gpbo_set_candidates_lattice(gpbo_ctx* ctx, const double* axes, const int32_t* sizes, int32_t d) {
+    if (!ctx) return GPBO_ERR_BAD_ARG;
+    if (!axes || !sizes) BADARG("set_candidates_lattice: null input");
+    if (!ctx->fitted) BADARG("set_candidates: fit first (the candidate width is the model's d)");
+    if (d != ctx->d) BADARG("set_candidates_lattice: the number of axes must equal the model's d");
+    LatticeDesc L{};
+    L.d = d;
+    L.split = (d + 1) / 2;       // a fixed rule: the grouping of the factors must not depend on how a lattice was cut into slabs
+    int64_t total = 0, m = 1;
+    L.P = 1;
+    L.Q = 1;
+    for (int t = 0; t < d; ++t) {
+        if (sizes[t] < 1) BADARG("set_candidates_lattice: every axis needs at least one point");
+        L.size[t] = sizes[t];
+        L.off[t] = (int)total;
+        total += sizes[t];
+        if (m > (int64_t)1 << 40) BADARG("set_candidates_lattice: lattice too large");
+        m *= sizes[t];
+        if (t < L.split) L.P *= sizes[t];
+        else L.Q *= sizes[t];
+    }
+    for (int64_t i = 0; i < total; ++i)
+        if (!std::isfinite(axes[i])) BADARG("set_candidates_lattice: coordinates must be finite");
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(reserve_candidates(ctx, m));
+    if (total > ctx->lat_axes_cap) {
+        CHK(dev_alloc(ctx, &ctx->lat_axes, (size_t)total));
+        ctx->lat_axes_cap = total;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->lat_axes, axes, (size_t)total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_lattice_points, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, L, (const double*)ctx->lat_axes, ctx->Xs,
+                       (long)m);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // axes is the caller's memory
+    ctx->lat = L;
+    ctx->lattice = true;
     return GPBO_OK;
 }
 

@@ -1610,6 +1610,18 @@ constexpr int ACQ_SPAN = 256 * ACQ_PER;
 // n_parts > 0: the incumbent is the maximum of inc_parts[0 .. n_parts) (n_parts <= 256: the second-stage results of the
 // max(mu) reduction), which every workgroup reduces for itself instead of waiting for a launch that does it once; workgroup 0
 // leaves it in inc_out[0] (incumbent) and inc_out[1] (max(mu)).  A maximum does not depend on the order it is taken in.
+// The maximum of up to 256 partial maxima, by every thread of a 256-thread workgroup (rv: 4 doubles of shared memory).
+__device__ __forceinline__ double block_max_of_parts(const double* __restrict__ parts, int n_parts, double* rv) {
+    const int tid = threadIdx.x;
+    double v = (tid < n_parts) ? parts[tid] : -INFINITY;
+    for (int o = 32; o > 0; o >>= 1) v = max_nan(v, __shfl_xor(v, o));
+    if ((tid & 63) == 0) rv[tid >> 6] = v;
+    __syncthreads();
+    const double r = max_nan(max_nan(rv[0], rv[1]), max_nan(rv[2], rv[3]));
+    __syncthreads();
+    return r;
+}
+
 template <bool STORE>
 __global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict__ mu, const double* __restrict__ var, long m, int acq,
                                                         double kappa, const double* __restrict__ inc_ptr, double* __restrict__ out,
@@ -1622,12 +1634,7 @@ __global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict
     const long base = (long)blockIdx.x * ACQ_SPAN;
     double inc;
     if (n_parts > 0) {
-        double v = (tid < n_parts) ? inc_parts[tid] : -INFINITY;
-        for (int o = 32; o > 0; o >>= 1) v = max_nan(v, __shfl_xor(v, o));
-        if ((tid & 63) == 0) rv[tid >> 6] = v;
-        __syncthreads();
-        inc = max_nan(max_nan(rv[0], rv[1]), max_nan(rv[2], rv[3]));
-        __syncthreads();                                   // rv is reused below
+        inc = block_max_of_parts(inc_parts, n_parts, rv);
         if (blockIdx.x == 0 && tid == 0) {
             inc_out[0] = inc;
             inc_out[1] = inc;
@@ -2480,11 +2487,15 @@ __global__ __launch_bounds__(256) void k_append_scalars(const double* __restrict
     }
 }
 
-// New row of W and the enlarged alpha, thread per column j <= n (n = size before the append):
+// New row of W and the enlarged alpha, per column j <= n (n = size before the append):
 //   W[n][j] = -(1/d_new) * sum_{i=j..n-1} l_i W[i][j]  (j < n; W[n][n] is already in place),
 //   alpha1[j] = alpha[j] = sum_{i=j..n} W[i][j] z_i   (W^T z over the enlarged model; the mean of this variant uses alpha = alpha1).
-// Neither is read by the sweep over the candidates, so the first workgroup(s) of the sweep's launch run this routine
-// beside it instead of two launches of their own in front of it.
+// Both sums are always formed as eight partial sums over (i - j) mod 8, joined pairwise -- by one thread here, by eight
+// threads in k_append_wrow: the same arithmetic, so the two routes of an append update the factor bit for bit alike.
+__device__ __forceinline__ double join8(const double (&p)[8]) { return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])); }
+
+// Neither result is read by the sweep over the candidates, so the first workgroup(s) of the streaming sweep's launch run
+// this routine beside it instead of launches of their own in front of it.
 __device__ __forceinline__ void append_wrow_alpha(int blk, double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
                                                   const double* __restrict__ scal, const double* __restrict__ zfw,
                                                   double* __restrict__ alpha1, double* __restrict__ alpha) {
@@ -2492,18 +2503,67 @@ __device__ __forceinline__ void append_wrow_alpha(int blk, double* __restrict__ 
     if (j > n) return;
     double a = 0.0, wn;
     if (j < n) {
-        double s = 0.0;
-        for (int i = j; i < n; ++i) {
-            const double w = W[(long)i * ld + j];
-            s += lvec[i] * w;
-            a += w * zfw[i];
+        double ps[8], pa[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ps[q] = pa[q] = 0.0;
+        int i = j;
+        for (; i + 8 <= n; i += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double w = W[(long)(i + q) * ld + j];
+                ps[q] = fma(lvec[i + q], w, ps[q]);
+                pa[q] = fma(w, zfw[i + q], pa[q]);
+            }
         }
-        wn = -s / scal[A_DNEW];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i + q < n) {
+                const double w = W[(long)(i + q) * ld + j];
+                ps[q] = fma(lvec[i + q], w, ps[q]);
+                pa[q] = fma(w, zfw[i + q], pa[q]);
+            }
+        wn = -join8(ps) / scal[A_DNEW];
+        a = join8(pa);
         W[(long)n * ld + j] = wn;
     } else {
         wn = W[(long)n * ld + n];
     }
-    a += wn * zfw[n];
+    a = fma(wn, zfw[n], a);
+    alpha1[j] = a;
+    alpha[j] = a;
+}
+
+// The same update in a launch of its own (the lattice route of an append has no streaming sweep to ride along with): 32
+// columns x 8 threads per workgroup, thread q of a column forms partial sum q.
+__global__ __launch_bounds__(256) void k_append_wrow(double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
+                                                     const double* __restrict__ scal, const double* __restrict__ zfw,
+                                                     double* __restrict__ alpha1, double* __restrict__ alpha) {
+    __shared__ double ss[8][33], sa[8][33];
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + c;
+    double ps = 0.0, pa = 0.0;
+    if (j < n) {
+        for (int i = j + q; i < n; i += 8) {
+            const double w = W[(long)i * ld + j];
+            ps = fma(lvec[i], w, ps);
+            pa = fma(w, zfw[i], pa);
+        }
+    }
+    ss[q][c] = ps;
+    sa[q][c] = pa;
+    __syncthreads();
+    if (q != 0 || j > n) return;
+    double a = 0.0, wn;
+    if (j < n) {
+        const double s8[8] = {ss[0][c], ss[1][c], ss[2][c], ss[3][c], ss[4][c], ss[5][c], ss[6][c], ss[7][c]};
+        const double a8[8] = {sa[0][c], sa[1][c], sa[2][c], sa[3][c], sa[4][c], sa[5][c], sa[6][c], sa[7][c]};
+        wn = -join8(s8) / scal[A_DNEW];
+        a = join8(a8);
+        W[(long)n * ld + j] = wn;
+    } else {
+        wn = W[(long)n * ld + n];
+    }
+    a = fma(wn, zfw[n], a);
     alpha1[j] = a;
     alpha[j] = a;
 }

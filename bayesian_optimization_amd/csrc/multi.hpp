@@ -476,6 +476,43 @@ int gpbo_multi_set_candidates_uniform(gpbo_multi* mg, uint64_t seed, int64_t row
     return GPBO_OK;
 }
 
+int gpbo_multi_set_candidates_lattice(gpbo_multi* mg, const double* axes, const int32_t* sizes, int32_t d) {
+    if (!mg) return GPBO_ERR_BAD_ARG;
+    if (!axes || !sizes || d < 1 || d > MAX_D) MBADARG("set_candidates_lattice: null input or bad number of axes");
+    if (!mg->fitted) MBADARG("set_candidates_lattice: fit first (the candidate width is the model's d)");
+    for (int t = 0; t < d; ++t)
+        if (sizes[t] < 1) MBADARG("set_candidates_lattice: every axis needs at least one point");
+    const int N = (int)mg->ctx.size();
+    // slabs along axis 0: every context's block is again a lattice, contiguous in the lexicographic order
+    int64_t total = 0, inner = 1;
+    for (int t = 0; t < d; ++t) total += sizes[t];
+    for (int t = 1; t < d; ++t) inner *= sizes[t];
+    std::vector<int64_t> off((size_t)N + 1, 0), lo((size_t)N), hi((size_t)N);
+    for (int i = 0; i < N; ++i) {
+        block_range(sizes[0], i, N, &lo[(size_t)i], &hi[(size_t)i]);
+        off[(size_t)i] = lo[(size_t)i] * inner;
+        off[(size_t)i + 1] = hi[(size_t)i] * inner;
+    }
+    mg->xoff.assign((size_t)N + 1, 0);
+    mg->poff.assign((size_t)N + 1, 0);
+    std::vector<std::vector<double>> ax((size_t)N);
+    std::vector<std::vector<int32_t>> sz((size_t)N);
+    for (int i = 0; i < N; ++i) {
+        if (hi[(size_t)i] <= lo[(size_t)i]) continue;
+        ax[(size_t)i].assign(axes + lo[(size_t)i], axes + hi[(size_t)i]);
+        ax[(size_t)i].insert(ax[(size_t)i].end(), axes + sizes[0], axes + total);
+        sz[(size_t)i].assign(sizes, sizes + d);
+        sz[(size_t)i][0] = (int32_t)(hi[(size_t)i] - lo[(size_t)i]);
+    }
+    CHK(run_all(mg, [&](int i) { return hi[(size_t)i] > lo[(size_t)i]; }, [&](int i) {
+        return gpbo_set_candidates_lattice(mg->ctx[(size_t)i], ax[(size_t)i].data(), sz[(size_t)i].data(), d);
+    }));
+    for (int i = 0; i < N; ++i)
+        if (hi[(size_t)i] <= lo[(size_t)i]) mg->ctx[(size_t)i]->xs_rows = 0;      // an empty block holds no candidates
+    mg->xoff = off;
+    return GPBO_OK;
+}
+
 int gpbo_multi_posterior(gpbo_multi* mg, double* mu_max_out) {
     if (!mg) return GPBO_ERR_BAD_ARG;
     return multi_posterior(mg, mu_max_out);

@@ -250,32 +250,72 @@ class ShardedLoop:
     the model needs no exchange; per iteration the data path has two exchanges: all-reduce(MAX) of max(Mu) (one double) and
     one all-gather of (acquisition max, global index, the d coordinates of that candidate) per rank."""
 
-    def __init__(self, gp, candidates_local, offset: int = 0):
+    def __init__(self, gp, candidates_local, offset: int = 0, exchange: bool = True):
+        """exchange=False: this rank's loop is its own (independent replicas under one launcher): nothing is exchanged."""
         self.gp = gp
         self.X = np.ascontiguousarray(candidates_local, dtype=np.float64)
         self.offset = int(offset)
+        self.exchange = bool(exchange) and _is_dist()
         gp.set_candidates(self.X)
-        self.mu_max = allreduce_max(gp.posterior(), gp.device)
+        self.mu_max = self._max(gp.posterior())
+
+    def _max(self, v):
+        return allreduce_max(v, self.gp.device) if self.exchange else v
+
+    @classmethod
+    def on_lattice(cls, gp, axes, exchange: bool = True):
+        """The same loop on a candidate LATTICE (every combination of the per-axis coordinates, last axis fastest): the ranks
+        take contiguous slabs of axis 0, each slab again a lattice, generated in HBM (GP.set_candidates_lattice).  With the
+        RBF kernel an append then costs one small matrix product per rank instead of a pass over a resident (n, m / ranks)
+        matrix, and a candidate's numbers do not depend on the number of ranks."""
+        self = cls.__new__(cls)
+        self.exchange = bool(exchange) and _is_dist()
+        axes = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1)) for a in axes]
+        rank = dist.get_rank() if self.exchange else 0
+        world = dist.get_world_size() if self.exchange else 1
+        lo, hi = shard_range(len(axes[0]), rank, world)
+        if hi <= lo:
+            raise ValueError('on_lattice: axis 0 has %d points, fewer than the %d ranks' % (len(axes[0]), world))
+        self.gp = gp
+        self.X = None
+        self.axes = [axes[0][lo:hi]] + axes[1:]
+        self.offset = int(lo) * int(np.prod([len(a) for a in axes[1:]], dtype=np.int64))
+        gp.set_candidates_lattice(self.axes)
+        self.mu_max = self._max(gp.posterior())
+        return self
+
+    def _point(self, idx):
+        """Coordinates of local candidate idx."""
+        if self.X is not None:
+            return self.X[idx].copy()
+        x = np.empty(len(self.axes))
+        r = int(idx)
+        for t in range(len(self.axes) - 1, -1, -1):
+            r, g = divmod(r, len(self.axes[t]))
+            x[t] = self.axes[t][g]
+        return x
 
     def propose(self, acq=0, kappa=0.01):
         """(global index, acquisition value, coordinates) of the next point; identical on every rank."""
         idx, best = self.gp.acquire(acq, kappa, 2, self.mu_max)
-        gbest, gidx, x = global_argmax_payload(best, idx, self.offset, self.X[idx], self.gp.device)
+        if not self.exchange:
+            return idx + self.offset, best, self._point(idx)
+        gbest, gidx, x = global_argmax_payload(best, idx, self.offset, self._point(idx), self.gp.device)
         return gidx, gbest, x
 
     def observe(self, x_new, y_new):
-        self.mu_max = allreduce_max(self.gp.append(x_new, y_new), self.gp.device)
+        self.mu_max = self._max(self.gp.append(x_new, y_new))
         return self.mu_max
 
     def step(self, x_new, y_new, acq=0, kappa=0.01):
         """observe(x_new, y_new) then propose(acq, kappa): one loop iteration.  With a single rank the two halves share
         one library call and one host synchronisation (the incumbent max(Mu) needs no exchange); the picks are the same."""
-        if _is_dist():
+        if self.exchange:
             self.observe(x_new, y_new)
             return self.propose(acq, kappa)
         self.mu_max, idx, best = self.gp.append_acquire(x_new, y_new, acq, kappa, 0)      # incumbent = max(Mu), on the device
         gidx = idx + self.offset
-        return gidx, best, self.X[idx].copy()
+        return gidx, best, self._point(idx)
 
 
 def sharded_lml(gp, xTrain, yTrain, thetas, sigmas, kernel=0, grad=True):

@@ -125,6 +125,22 @@ class GP:
         self.m = self._xs_rows = int(m)
         return self
 
+    def set_candidates_lattice(self, axes):
+        """Candidates = every combination of the per-axis coordinates in ``axes`` (one 1-D array per input dimension),
+        lexicographic with the last axis fastest -- np.stack(np.meshgrid(*axes, indexing='ij'), -1).reshape(-1, d) --
+        generated in HBM.  With the RBF kernel and reserve_appends(), append / append_acquire then update the posterior
+        through one small matrix product instead of a pass over a resident (n, m) matrix."""
+        ax = [_f64(np.asarray(a).reshape(-1), 1) for a in axes]
+        if len(ax) != self.d:
+            raise ValueError('%d axes given, the model has %d input columns' % (len(ax), self.d))
+        flat = _f64(np.concatenate(ax), 1)
+        sizes = (C.c_int32 * len(ax))(*[a.shape[0] for a in ax])
+        try:
+            self._check(self._lib.gpbo_set_candidates_lattice(self._h, L.dptr(flat), sizes, len(ax)))
+        finally:
+            self._sync_shape()
+        return self
+
     def posterior(self):
         """Mean/variance for the resident candidates (kept in HBM); returns max(mu)."""
         mm = C.c_double()
@@ -458,6 +474,18 @@ class MultiGP:
             raise ValueError('xTest has %d columns, the model %d' % (Xs.shape[1], self.d))
         try:
             self._check(self._lib.gpbo_multi_set_candidates(self._h, Xs.ctypes.data_as(C.c_void_p), Xs.shape[0], 0))
+        finally:
+            self._sync_shape()
+        return self
+
+    def set_candidates_lattice(self, axes):
+        ax = [_f64(np.asarray(a).reshape(-1), 1) for a in axes]
+        if len(ax) != self.d:
+            raise ValueError('%d axes given, the model has %d input columns' % (len(ax), self.d))
+        flat = _f64(np.concatenate(ax), 1)
+        sizes = (C.c_int32 * len(ax))(*[a.shape[0] for a in ax])
+        try:
+            self._check(self._lib.gpbo_multi_set_candidates_lattice(self._h, L.dptr(flat), sizes, len(ax)))
         finally:
             self._sync_shape()
         return self

@@ -274,9 +274,12 @@ def sweep_block(a, config, gp, world, rank, backend, steps, warmup, with_cpu):
     return out
 
 
-def cfg4_block(a, gp, world, rank, backend, iters, warmup):
+def cfg4_block(a, gp, world, rank, backend, iters, warmup, lattice=False):
     """cfg4: BayesOpt_v4-style loop, theta frozen: EI iterations with incremental append on a 64^4 candidate lattice
-    (a step = one iteration: acquisition + argmax + border-append + the HBM-streaming sweep of the resident V).
+    (a step = one iteration: acquisition + argmax + border-append + the update of every candidate's mean and variance).
+    lattice=False: the candidates are handed over as a plain array of points and the update streams the resident V (what
+    any candidate set gets).  lattice=True: they are handed over as a lattice (per-axis coordinates) and the update is one
+    product of per-axis kernel factors on the MFMA pipe followed by the same read-modify-write of mean / variance.
     Returns the JSON dictionary on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
@@ -296,14 +299,14 @@ def cfg4_block(a, gp, world, rank, backend, iters, warmup):
     sharded = world > 1 and not a.replicas       # candidate rows (and the resident V) split over the ranks: one loop, strong scaling
     lo, hi = gdist.shard_range(m_total, rank, world) if sharded else (0, m_total)
     # lexicographic order, as the notebooks' nested loops; built per block from the flat index
-    ii = np.arange(lo, hi)
+    ii = np.arange(lo, hi) if not lattice else np.arange(0)
     grid = np.stack([g1[(ii // side ** (d - 1 - k)) % side] for k in range(d)], -1)
     f = lambda x: np.exp(-8 * np.sum((x - 0.37) ** 2, -1)) + 0.5 * np.exp(-20 * np.sum((x - 0.8) ** 2, -1))
     X0 = synth.uniform(4 if sharded else 4 + rank, n0 * d).reshape(n0, d)     # replicas: every rank runs its own independent loop
     gp.reserve_appends(iters + warmup)
     gp.fit(X0, f(X0), np.full(d, 0.25), 1e-2, variant=bo.VARIANT_SINGLE)
-    loop = gdist.ShardedLoop(gp, grid, lo)
-    m = len(grid)
+    loop = gdist.ShardedLoop.on_lattice(gp, [g1] * d, exchange=sharded) if lattice else gdist.ShardedLoop(gp, grid, lo, exchange=sharded)
+    m = gp.m
     sweep_ms, bytes_alg = 0.0, 0.0
     picked = []
     # an iteration = append the point picked last + sweep + pick the next one (ShardedLoop.step)
@@ -322,7 +325,10 @@ def cfg4_block(a, gp, world, rank, backend, iters, warmup):
         jj, ei, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
         if sample:
             sweep_ms += gp.timings()['append_sweep_ms']
-            bytes_alg += m * (8.0 * n_before + 8 + 32 + 8 * d)     # V read + new V row + (mu, var r/w; sum v^2 r/w) + candidates
+            if lattice:       # mean r/w, sum v^2 r/w, variance w; the two factor matrices of the product ((P + Q)(n + 1) doubles) once
+                bytes_alg += m * 40.0 + 8.0 * (n_before + 1) * (side ** ((d + 1) // 2) + side ** (d // 2))
+            else:             # V read + new V row + (mu, var r/w; sum v^2 r/w) + candidates
+                bytes_alg += m * (8.0 * n_before + 8 + 32 + 8 * d)
             timed += 1
     gp.set_timing(True)
     barrier()
@@ -339,10 +345,13 @@ def cfg4_block(a, gp, world, rank, backend, iters, warmup):
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'cfg4: %d EI iterations, incremental append (theta frozen, single-factor posterior), '
                                '%d^4 = %d candidate lattice, d=4, n0=%d, sigmaY=1e-2; %s'
-                               % (iters, side, m_total, n0, 'candidate rows and resident V split over the GPUs, one loop'
-                                  if sharded else 'one independent loop per GPU'),
+                               % (iters, side, m_total, n0, ('candidate rows and resident V split over the GPUs, one loop'
+                                  if sharded else 'one independent loop per GPU') +
+                                  ('; candidates given as a lattice: per-append update = one (%d x %d x n) product of per-axis kernel '
+                                   'factors, no resident V' % (side ** ((d + 1) // 2), side ** (d // 2)) if lattice else
+                                   '; candidates given as points: per-append update streams the resident V')),
                    'n_final': gp.n, 'best_y': float(gp.y_max), 'picked_head': [int(j) for j in picked[:16]]},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_append_sweep', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'roofline': {'bound': 'hbm', 'kernel': 'k_lattice_gemm_update (+ factor build)' if lattice else 'k_append_sweep', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': sweep_ms / max(timed, 1),
                      'bytes_per_launch_avg': bytes_alg / max(timed, 1), 'launches_timed': timed}}
 
@@ -462,7 +471,7 @@ def secondary(a):
     world, rank, local_rank, backend = _dist_setup()
     gp = GP(local_rank)
     if a.config == 'cfg4':
-        out = cfg4_block(a, gp, world, rank, backend, a.iters, a.warmup)
+        out = cfg4_block(a, gp, world, rank, backend, a.iters, a.warmup, lattice=a.lattice)
     else:
         out = cfg5_block(a, gp, world, rank, backend, a.settings if a.settings else max(1, 256 // world), a.steps, a.warmup)
     if rank == 0:
@@ -509,6 +518,7 @@ def main():
     ap.add_argument('--no-cfg45', action='store_true', help='leave the lattice-loop and likelihood-sweep blocks out of the default line')
     ap.add_argument('--iters', type=int, default=200, help='cfg4: EI iterations')
     ap.add_argument('--side', type=int, default=64, help='cfg4: points per axis of the candidate lattice')
+    ap.add_argument('--lattice', action='store_true', help='cfg4: hand the candidates over as a lattice (per-axis coordinates)')
     ap.add_argument('--replicas', action='store_true', help='cfg4 with several GPUs: independent loops instead of one sharded loop')
     ap.add_argument('--settings', type=int, default=0, help='cfg5: settings per GPU (default 256 / gpus)')
     ap.add_argument('--rehearse', action='store_true', help='launch/exchange plumbing only, on the CPU (no GPU work, no measurement)')
@@ -567,6 +577,12 @@ def main():
         gp4.close()
         if rank == 0:
             out['cfg4'] = {k: blk[k] for k in keys}
+        gp4 = GP(local_rank)
+        blk2 = cfg4_block(a, gp4, world, rank, backend, 200, 1, lattice=True)
+        gp4.close()
+        if rank == 0:
+            out['cfg4_lattice'] = {k: blk2[k] for k in keys}
+            out['cfg4_lattice']['same_picks_as_cfg4'] = blk2['config']['picked_head'] == blk['config']['picked_head']
         gp5 = GP(local_rank)
         blk = cfg5_block(a, gp5, world, rank, backend, 32, 1, 1)
         gp5.close()

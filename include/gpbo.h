@@ -70,8 +70,8 @@ typedef struct gpbo_timings {
     double acquire_ms;     /* acquisition + argmax */
     double trmm_flops;     /* algorithmic flops of the trmm launches: n_pad-free count n^2 per candidate */
     double append_total_ms;  /* last gpbo_append: factor update + sweep + max(mu) */
-    double append_sweep_ms;  /* the HBM-streaming V sweep of the last gpbo_append */
-    double reserved[1];
+    double append_sweep_ms;  /* the update of the candidates' posterior inside the last gpbo_append */
+    double append_route;     /* how that update ran: 0 = pass over the resident V, 1 = product of per-axis factors (lattice) */
 } gpbo_timings;
 
 /* Device-side description of a fitted model, for broadcasting it to other ranks
@@ -111,6 +111,16 @@ int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xs, int64_t m, int32_t on_d
  * bayesian_optimization_amd/synth.py:uniform on the host.  Stands where the notebooks build their candidate grid on
  * the host (BayesOpt_v4.ipynb:705-714) for benchmark sets too large to generate and upload (64 M x 8 = 4.3 GB). */
 int gpbo_set_candidates_uniform(gpbo_ctx* ctx, uint64_t seed, int64_t row_offset, int64_t m);
+
+/* The candidate grid the notebooks build with nested loops (BayesOpt_v4.ipynb:705-714, the 400-point grid at :248): every
+ * combination of per-axis coordinates, in lexicographic order with the LAST axis fastest, generated in HBM.  axes: the
+ * coordinates of axis 0, then axis 1, ... (sizes[t] of them for axis t; d = the model's d); m = prod sizes[t].  Everything
+ * that works on a candidate set works on this one.  In addition, with the RBF kernel and a model fitted after
+ * gpbo_reserve_appends (single-factor variant), gpbo_append / gpbo_append_acquire take the new row of L^-1 K(X, X*) as ONE
+ * matrix product of per-axis kernel factors on the fp64 MFMA pipe (the kernel is a product over the axes) instead of a
+ * pass over a resident (n x m) matrix, which is then not allocated at all: same posterior to rounding, a fraction of the
+ * memory traffic.  (GPBO_LATTICE=0 in the environment keeps the streaming route, for comparison.) */
+int gpbo_set_candidates_lattice(gpbo_ctx* ctx, const double* axes, const int32_t* sizes, int32_t d);
 
 /* Pass 1 over the resident candidates: posterior mean and variance
  * (BayesOpt_v4.ipynb:135,146,149-151; only diag(Cov) is formed) kept in HBM, and the
@@ -315,6 +325,9 @@ int gpbo_multi_kriging_fit(gpbo_multi* mg, const double* X, const double* y, int
 int gpbo_multi_set_candidates(gpbo_multi* mg, const double* Xs, int64_t m, int32_t on_device);
 /* Context i generates rows [row_offset + lo_i, row_offset + hi_i) of the synthetic set itself. */
 int gpbo_multi_set_candidates_uniform(gpbo_multi* mg, uint64_t seed, int64_t row_offset, int64_t m);
+/* gpbo_set_candidates_lattice over the contexts: slabs along axis 0, each again a lattice (contexts beyond the number of axis-0
+ * points get no candidates). */
+int gpbo_multi_set_candidates_lattice(gpbo_multi* mg, const double* axes, const int32_t* sizes, int32_t d);
 int gpbo_multi_posterior(gpbo_multi* mg, double* mu_max_out);
 int gpbo_multi_acquire(gpbo_multi* mg, int32_t acq, double kappa, int32_t incumbent_mode, double incumbent, int64_t* argmax_out,
                        double* best_out);
