@@ -106,19 +106,28 @@ for c in range(cases):
     if c % 10 == 9:
         print('[%d/%d] %.0f s, mismatches %d' % (c + 1, cases, time.time() - t0, bad), flush=True)
 
-# the frozen-theta loop: replicated model, split lattice
-for c in range(max(cases // 10, 2)):
+# the frozen-theta loop: replicated model, split candidates -- random points (streaming update) or a random lattice cut
+# into slabs along its first axis (update by a product of per-axis kernel factors)
+for c in range(max(cases // 5, 4)):
     k = int(rng.choice([2, 3, 4]))
     mg = multis[k]
-    d = int(rng.integers(1, 4)); n0 = int(rng.integers(2, 40)); m = int(rng.choice([50, 333, 2000])); steps = int(rng.integers(1, 12))
+    d = int(rng.integers(1, 5)); n0 = int(rng.integers(2, 40)); m = int(rng.choice([50, 333, 2000])); steps = int(rng.integers(1, 12))
     X = rng.random((n0, d)); f = lambda x: np.exp(-6 * np.sum((x - 0.4) ** 2, -1)); Xs = rng.random((m, d))
+    axes = None
+    if c % 2 == 1:
+        axes = [np.sort(rng.random(int(rng.integers(k, 12)))) for _ in range(d)]      # at least one axis-0 point per context
+        Xs = np.stack(np.meshgrid(*axes, indexing='ij'), -1).reshape(-1, d)
+        m = len(Xs)
     theta = np.full(d, 0.3)
     picks = []
     for g in (one, mg):
         g.set_chunk(0)
         g.reserve_appends(steps)
         g.fit(X, f(X), theta, 1e-2, variant=bo.VARIANT_SINGLE)
-        g.set_candidates(Xs)
+        if axes is None:
+            g.set_candidates(Xs)
+        else:
+            g.set_candidates_lattice(axes)
         mu_max = g.posterior()
         j, v = g.acquire(bo.ACQ_EI, 0.01, bo.INCUMBENT_GIVEN, mu_max)
         seq = [(j, v, mu_max)]
@@ -128,7 +137,7 @@ for c in range(max(cases // 10, 2)):
         picks.append((seq, g.read(), g.theta1, g.nll))
         g.reserve_appends(0)
     if not (picks[0][0] == picks[1][0] and all(same(u, v) for u, v in zip(picks[0][1], picks[1][1])) and picks[0][2:] == picks[1][2:]):
-        report('append loop', dict(k=k, d=d, n0=n0, m=m, steps=steps))
+        report('append loop', dict(k=k, d=d, n0=n0, m=m, steps=steps, lattice=axes is not None))
 
 print('cases %d  mismatches %d  (%.0f s)' % (cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
