@@ -617,7 +617,8 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     }
     const bool keep_inc = (ctx->variant == GPBO_VARIANT_SINGLE && ctx->reserve > 0 && ctx->have_factor);   // also after the last append
     // lattice candidates + RBF: appends take the new row of V from a product of per-axis factors, V itself is not kept
-    const bool lat = keep_inc && ctx->lattice && ctx->kernel == GPBO_KERNEL_RBF && lattice_route_enabled();
+    // (only where the two factor matrices are small beside V: not for one axis, where A would have a row per candidate)
+    const bool lat = keep_inc && ctx->lattice && ctx->kernel == GPBO_KERNEL_RBF && 2 * (ctx->lat.P + ctx->lat.Q) <= ctx->m && lattice_route_enabled();
     const bool keep_v = keep_inc && !lat;
     if (keep_v) {
         const int64_t rows = ctx->n + ctx->reserve_left;

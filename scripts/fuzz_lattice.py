@@ -45,7 +45,9 @@ for c in range(cases):
             Xa.append(grid[j][None, :])
             mu_max, j, v = gp.append_acquire(grid[j], float(f(grid[j])), bo.ACQ_EI, 0.01, bo.INCUMBENT_MAX_MU)
             picks.append(j)
-        assert gp.timings()['append_route'] == (1.0 if lat else 0.0)
+        sizes = [len(x) for x in axes]
+        P, Q = int(np.prod(sizes[:(d + 1) // 2])), int(np.prod(sizes[(d + 1) // 2:]))
+        assert gp.timings()['append_route'] == (1.0 if lat and 2 * (P + Q) <= m else 0.0)     # (tiny or one-axis lattices stream)
         mu, var = gp.read()
         runs.append(dict(picks=picks, mu=mu, var=var, th1=gp.theta1, nll=gp.nll, X=np.vstack(Xa)))
         gp.close()
