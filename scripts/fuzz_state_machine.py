@@ -87,7 +87,13 @@ for seq in range(seqs):
                     except REFUSE:
                         pass
                     continue
-                gp.set_candidates(Xs)
+                if rng.random() < 0.4:      # the same kind of set handed over as a lattice (per-axis coordinates)
+                    axes = [np.sort(rng.random(int(rng.integers(1, 9)))) * (4.0 if S['kind'] == 'kriging' else 1.0) for _ in range(d)]
+                    gp.set_candidates_lattice(axes)
+                    Xs = np.stack(np.meshgrid(*axes, indexing='ij'), -1).reshape(-1, d)
+                    counts['lattice'] = counts.get('lattice', 0) + 1
+                else:
+                    gp.set_candidates(Xs)
                 S.update(Xs=Xs, post=None, inc=False, acq=False)
             elif op == 'posterior':
                 usable = S['kind'] is not None and S['Xs'] is not None      # (an uploaded posterior is simply replaced)
