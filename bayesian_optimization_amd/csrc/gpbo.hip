@@ -617,8 +617,9 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     }
     const bool keep_inc = (ctx->variant == GPBO_VARIANT_SINGLE && ctx->reserve > 0 && ctx->have_factor);   // also after the last append
     // lattice candidates + RBF: appends take the new row of V from a product of per-axis factors, V itself is not kept
-    // (only where the two factor matrices are small beside V: not for one axis, where A would have a row per candidate)
-    const bool lat = keep_inc && ctx->lattice && ctx->kernel == GPBO_KERNEL_RBF && 2 * (ctx->lat.P + ctx->lat.Q) <= ctx->m && lattice_route_enabled();
+    // (not where the fast axes have a single combination -- one axis, or trailing axes of one point: A would be as large as V.
+    //  The test must not look at axis 0: slabs of one lattice on several contexts have to take the same route.)
+    const bool lat = keep_inc && ctx->lattice && ctx->kernel == GPBO_KERNEL_RBF && ctx->lat.Q >= 2 && lattice_route_enabled();
     const bool keep_v = keep_inc && !lat;
     if (keep_v) {
         const int64_t rows = ctx->n + ctx->reserve_left;

@@ -119,8 +119,8 @@ int gpbo_set_candidates_uniform(gpbo_ctx* ctx, uint64_t seed, int64_t row_offset
  * gpbo_reserve_appends (single-factor variant), gpbo_append / gpbo_append_acquire take the new row of L^-1 K(X, X*) as ONE
  * matrix product of per-axis kernel factors on the fp64 MFMA pipe (the kernel is a product over the axes) instead of a
  * pass over a resident (n x m) matrix, which is then not allocated at all: same posterior to rounding, a fraction of the
- * memory traffic (lattices with at least two axes whose factor matrices are small beside that matrix: 2 (P + Q) <= m with P, Q
- * the number of combinations of the first ceil(d / 2) and of the remaining axes).  (GPBO_LATTICE=0 in the environment keeps the streaming route, for comparison.) */
+ * memory traffic (lattices whose axes ceil(d / 2) .. d-1 have at least two combinations: with one axis there is nothing to
+ * factorise and the pass over the resident matrix stays).  (GPBO_LATTICE=0 in the environment keeps the streaming route, for comparison.) */
 int gpbo_set_candidates_lattice(gpbo_ctx* ctx, const double* axes, const int32_t* sizes, int32_t d);
 
 /* Pass 1 over the resident candidates: posterior mean and variance

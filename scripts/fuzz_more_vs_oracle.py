@@ -189,6 +189,10 @@ for c in range(cases):
                 terms = np.nan_to_num(sg2 * np.exp(-0.5 * ((mu2[fin] - inc - kappa) / sg2) ** 2), nan=0.0, posinf=0.0)
             diff = np.maximum(diff - 1e-14 * terms, 0.0)
         e = float(np.max(diff)) / max(float(np.max(np.abs(ref[fin]))), 1e-300) if fin.any() else 0.0
+        if e > worst[name] and e > 1e-13 and fin.any():
+            jw = int(np.argmax(diff))
+            print('  (largest deviation so far: %s m=%d mode=%d kappa=%g inc=%.17g mu=%.17g var=%.17g got=%.17g ref=%.17g max|ref|=%.3g)'
+                  % (name, m, mode, kappa, inc, mu2[fin][jw], var2[fin][jw], vals[fin][jw], ref[fin][jw], float(np.max(np.abs(ref[fin])))), flush=True)
         worst[name] = max(worst[name], e)
         nan_same = np.array_equal(np.isnan(vals), np.isnan(ref))
         own = int(np.argmax(vals))                      # np.argmax: the first NaN if there is one (0/0 where var = 0 and mu = incumbent)
