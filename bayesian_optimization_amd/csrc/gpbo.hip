@@ -68,6 +68,7 @@ struct gpbo_ctx {
     // as a matrix product of per-axis factors (lattice.hpp) and V is not kept
     bool lattice = false;       // the resident candidates are the full lattice of lat (lexicographic order)
     bool inc_lattice = false;   // the current incremental state (sres, latE, latB) is the lattice route's
+    bool var_stale = false;     // lattice-route appends since `var` was last written: the variance is theta1 (1 - sres[j])
     LatticeDesc lat{};
     double *lat_axes = nullptr, *latA = nullptr, *latB = nullptr, *latE = nullptr, *lat_bmax = nullptr;
     int64_t lat_axes_cap = 0, lat_kcap = 0, lat_ppad = 0, lat_qpad = 0, lat_smax = 0, lat_a_cap = 0, lat_b_cap = 0, lat_e_cap = 0,
@@ -723,6 +724,7 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     ctx->have_acq = false;
     ctx->inc_valid = keep_inc;
     ctx->inc_lattice = lat;
+    ctx->var_stale = false;
     if (mu_max_out) *mu_max_out = mu_max;
     return GPBO_OK;
 }
@@ -788,7 +790,8 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new, bool defer_
                            ctx->latA, (long)ctx->lat_kcap, kpad);
         hipLaunchKernelGGL(k_lattice_gemm_update, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, ctx->stream, (const double*)ctx->latA,
                            (long)ctx->lat_kcap, (const double*)ctx->latB, (long)ctx->lat_qpad, kpad, ctx->lat.P, ctx->lat.Q, tiles_q,
-                           (const double*)ctx->scal, (const double*)ctx->params, ctx->sres, ctx->mu, ctx->var, ctx->lat_bmax);
+                           (const double*)ctx->scal, ctx->sres, ctx->mu, ctx->lat_bmax);
+        ctx->var_stale = true;
         ctx->sweep_parts = tiles;
         ctx->sweep_part_buf = ctx->lat_bmax;
     } else {
@@ -839,14 +842,17 @@ int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incum
     else
         BADARG("acquire: unknown incumbent mode");
     const unsigned blocks = (unsigned)((ctx->m + ACQ_SPAN - 1) / ACQ_SPAN);
+    // after lattice-route appends the variance array has not been written: the pass forms the variance from sum v^2
+    const double* vsrc = ctx->var_stale ? (const double*)ctx->sres : (const double*)ctx->var;
+    const double* c01 = ctx->var_stale ? (const double*)(ctx->params + P_C0) : (const double*)nullptr;
     if (store)
-        hipLaunchKernelGGL(k_acquire_argmax<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, (const double*)ctx->var,
+        hipLaunchKernelGGL(k_acquire_argmax<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, vsrc,
                            (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi, inc_parts, n_parts,
-                           ctx->inc_dev);
+                           ctx->inc_dev, c01);
     else
-        hipLaunchKernelGGL(k_acquire_argmax<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, (const double*)ctx->var,
+        hipLaunchKernelGGL(k_acquire_argmax<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, vsrc,
                            (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi, inc_parts, n_parts,
-                           ctx->inc_dev);
+                           ctx->inc_dev, c01);
     // (the last argmax stage, over the `blocks` per-workgroup results, runs inside the end-of-step launch: step_fetch)
     HIPCHK(hipGetLastError());
     ctx->have_acq = store;       // (not stored: the array still holds the values of an earlier posterior)
@@ -1274,7 +1280,15 @@ int gpbo_read(gpbo_ctx* ctx, double* mu, double* var, double* acq, int64_t offse
     HIPCHK(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)count * sizeof(double);
     if (mu) HIPCHK(hipMemcpyAsync(mu, ctx->mu + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (var) HIPCHK(hipMemcpyAsync(var, ctx->var + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (var) {
+        if (ctx->var_stale) {      // lattice-route appends left the variance as sum v^2: fill the array now
+            hipLaunchKernelGGL(k_var_from_s, dim3((unsigned)((ctx->m + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)ctx->sres,
+                               (const double*)ctx->params, ctx->var, (long)ctx->m);
+            HIPCHK(hipGetLastError());
+            ctx->var_stale = false;
+        }
+        HIPCHK(hipMemcpyAsync(var, ctx->var + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (acq) HIPCHK(hipMemcpyAsync(acq, ctx->acq + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return GPBO_OK;
@@ -1826,6 +1840,7 @@ int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64
     ctx->inc_valid = false;
     HIPCHK(hipMemcpyAsync(ctx->mu, mu, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->var, var, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->var_stale = false;
     CHK(reduce_max(ctx, ctx->mu, m, ctx->inc_dev + 1));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_posterior = true;

@@ -1650,7 +1650,10 @@ __global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict
                                                         double kappa, const double* __restrict__ inc_ptr, double* __restrict__ out,
                                                         double* __restrict__ part_v, long* __restrict__ part_i,
                                                         const double* __restrict__ inc_parts = nullptr, int n_parts = 0,
-                                                        double* __restrict__ inc_out = nullptr) {
+                                                        double* __restrict__ inc_out = nullptr,
+                                                        const double* __restrict__ c01 = nullptr) {
+    // c01 != nullptr: `var` holds sum v^2 per candidate and the variance is c01[0] - c01[1] * var[j] (< 1e-60 -> 0), as the
+    // lattice route of an append leaves it
     __shared__ double rv[256];
     __shared__ long ri[256];
     const int tid = threadIdx.x;
@@ -1671,7 +1674,12 @@ __global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict
     for (int u = 0; u < ACQ_PER; ++u) {
         const long j = base + u * 256 + tid;
         if (j < m) {
-            const double r = acq_value(mu[j], var[j], inc, acq, kappa);
+            double vj = var[j];
+            if (c01) {
+                vj = c01[0] - c01[1] * vj;
+                if (vj < 1e-60) vj = 0.0;
+            }
+            const double r = acq_value(mu[j], vj, inc, acq, kappa);
             if (STORE) out[j] = r;
             if (better(r, j, bv, bi)) {
                 bv = r;

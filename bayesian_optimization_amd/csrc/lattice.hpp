@@ -9,7 +9,8 @@
 //     v_(p,q) = sum_i A[p][i] B[i][q],   A[p][i] = W[n][i] prod_{t < split} e_t(i, g_t(p)),   B[i][q] = prod_{t >= split} e_t(i, g_t(q)):
 // one P x Q x (n + 1) matrix product on the fp64 MFMA tile engine (P = Q = 4096, n <= 216 on a 64^4 lattice: 7 GFLOP)
 // in place of streaming the resident V (8 n m bytes: 29 GB at n = 216), and V need not be kept at all.  The epilogue of
-// the product is the rest of the update: s_j += v^2, mu_j += v z_new, var_j = theta1 (1 - s_j), max(mu) per workgroup.
+// the product is the rest of the update: s_j += v^2, mu_j += v z_new, max(mu) per workgroup (the variance theta1 (1 - s_j) is
+// formed from s_j where it is used).
 // Every candidate's sum runs over i in the same order whatever tile it sits in, so a lattice cut into slabs along its
 // first axis (several contexts or ranks) reproduces the one-context numbers bit for bit.
 #pragma once
@@ -91,12 +92,14 @@ __global__ __launch_bounds__(256) void k_lattice_A(LatticeDesc L, const double* 
 // v = A B on 64 x 64 quarter tiles (four workgroups per CU, so that the product phase of one tile runs beside the
 // read-modify-write phase of another: 0.174 against 0.206 ms per update on the 64^4 lattice with 128 x 128 tiles), then per
 // candidate j = row * Q + col:
-//   s_j += v^2 ; mu_j += v z_new ; var_j = theta1 (1 - s_j), < 1e-60 -> 0 ; the workgroup's max(mu) -> bmax[blockIdx.x].
+//   s_j += v^2 ; mu_j += v z_new ; the workgroup's max(mu) -> bmax[blockIdx.x].
+// The variance theta1 (1 - s_j) is NOT written (8 of 40 bytes per candidate): the acquisition pass forms it from s_j, and
+// the array is filled when somebody reads it (k_var_from_s).
 __global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update(const double* __restrict__ A, long lda, const double* __restrict__ B,
                                                                            long ldb, int kpad, long P, long Q, int tiles_q,
-                                                                           const double* __restrict__ scal, const double* __restrict__ params,
+                                                                           const double* __restrict__ scal,
                                                                            double* __restrict__ sres, double* __restrict__ mu,
-                                                                           double* __restrict__ var, double* __restrict__ bmax) {
+                                                                           double* __restrict__ bmax) {
     const int ib = (int)blockIdx.x / tiles_q, jb = (int)blockIdx.x % tiles_q;
     __shared__ double lds[QUARTER_LDS_DOUBLES];
     f64x4 acc[2][2];
@@ -107,7 +110,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update(const d
     gemm_tile_64x64<false>(A + (long)ib * QUARTER_M * lda, lda, B + (long)jb * 64, ldb, 0, kpad, acc, lds);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const double znew = scal[A_ZNEW];
-    const double c0 = params[P_C0], c1 = params[P_C1];
     double mx = -INFINITY;
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
@@ -125,9 +127,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update(const d
                     const double mnew = mu[j] + v * znew;
                     mu[j] = mnew;
                     mx = max_nan(mx, mnew);
-                    double vr = c0 - c1 * s;
-                    if (vr < 1e-60) vr = 0.0;
-                    var[j] = vr;
                 }
             }
         }
@@ -136,6 +135,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update(const d
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) bmax[blockIdx.x] = max_nan(max_nan(wm[0], wm[1]), max_nan(wm[2], wm[3]));
+}
+
+// var_j = c0 - c1 s_j (< 1e-60 -> 0) for all candidates: the variance array after lattice-route appends, on demand.
+__global__ __launch_bounds__(256) void k_var_from_s(const double* __restrict__ sres, const double* __restrict__ params, double* __restrict__ var,
+                                                    long m) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    double vr = params[P_C0] - params[P_C1] * sres[j];
+    if (vr < 1e-60) vr = 0.0;
+    var[j] = vr;
 }
 
 }  // namespace gpbo

@@ -325,8 +325,8 @@ def cfg4_block(a, gp, world, rank, backend, iters, warmup, lattice=False):
         jj, ei, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
         if sample:
             sweep_ms += gp.timings()['append_sweep_ms']
-            if lattice:       # mean r/w, sum v^2 r/w, variance w; the two factor matrices of the product ((P + Q)(n + 1) doubles) once
-                bytes_alg += m * 40.0 + 8.0 * (n_before + 1) * (side ** ((d + 1) // 2) + side ** (d // 2))
+            if lattice:       # mean r/w, sum v^2 r/w (the variance is formed from it on use); the two factor matrices ((P + Q)(n + 1) doubles) once
+                bytes_alg += m * 32.0 + 8.0 * (n_before + 1) * (side ** ((d + 1) // 2) + side ** (d // 2))
             else:             # V read + new V row + (mu, var r/w; sum v^2 r/w) + candidates
                 bytes_alg += m * (8.0 * n_before + 8 + 32 + 8 * d)
             timed += 1
