@@ -161,3 +161,77 @@ def test_slice_bounds_tile_the_range():
         for parts in (1, 2, 3, 7):
             edges = [gdist.slice_bounds(n, parts, s) for s in range(parts)]
             assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[i][1] == edges[i + 1][0] for i in range(parts - 1))
+
+
+class _LatticeStandin:
+    """A context whose 'posterior' and 'acquisition' are fixed functions of a candidate's COORDINATES, so that the loop's
+    host logic on lattice slabs (offsets, decoding an index into coordinates, the exchanges) can be checked without a GPU."""
+    device = None
+
+    def set_candidates_lattice(self, axes):
+        self.X = np.stack(np.meshgrid(*axes, indexing='ij'), -1).reshape(-1, len(axes))
+        self.m = len(self.X)
+        self.seen = []
+
+    def _score(self):
+        s = np.sin(7 * self.X[:, 0] + 3 * self.X[:, 1]) + np.cos(5 * self.X[:, 2])
+        for x in self.seen:
+            s = s - 3.0 * np.exp(-50 * np.sum((self.X - x) ** 2, 1))
+        return s
+
+    def posterior(self):
+        return float(self._score().max())
+
+    def acquire(self, acq, kappa, mode, incumbent):
+        s = self._score()
+        i = int(np.argmax(s))
+        return i, float(s[i])
+
+    def append(self, x, y):
+        self.seen.append(np.asarray(x, dtype=np.float64))
+        return self.posterior()
+
+    def append_acquire(self, x, y, acq, kappa, mode):      # what a single rank calls: both halves in one library call
+        mu_max = self.append(x, y)
+        i, v = self.acquire(acq, kappa, mode, mu_max)
+        return mu_max, i, v
+
+
+def _lattice_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        axes = [np.linspace(0, 1, 7), np.linspace(0, 1, 5), np.linspace(0, 1, 4)]
+        loop = gdist.ShardedLoop.on_lattice(_LatticeStandin(), axes)
+        picks = []
+        gidx, best, x = loop.propose()
+        for _ in range(6):
+            picks.append((int(gidx), float(best), tuple(x)))
+            gidx, best, x = loop.step(x, 0.0)
+        q.put((rank, loop.offset, picks))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lattice_loop_on_slabs_of_axis_0_matches_one_process():
+    """ShardedLoop.on_lattice on 3 ranks (7 axis-0 points: slabs of 3, 2, 2): offsets are whole slabs, every rank reports the
+    same global index, value and coordinates, and the sequence equals the one-process loop's."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lattice_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [0, 3 * 20, 5 * 20]
+    assert res[0][2] == res[1][2] == res[2][2]
+    axes = [np.linspace(0, 1, 7), np.linspace(0, 1, 5), np.linspace(0, 1, 4)]
+    one = gdist.ShardedLoop.on_lattice(_LatticeStandin(), axes)
+    grid = np.stack(np.meshgrid(*axes, indexing='ij'), -1).reshape(-1, 3)
+    gidx, best, x = one.propose()
+    for k in range(6):
+        assert (int(gidx), float(best), tuple(x)) == res[0][2][k] and np.array_equal(x, grid[gidx])
+        gidx, best, x = one.step(x, 0.0)
