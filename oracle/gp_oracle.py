@@ -426,3 +426,66 @@ def cg_optim_wrap(X, y, sigmaY, x0, starts, alpha, beta, niter, normalize, kerne
         if fopt > f0:                                                          # :508
             xopt, fopt = xh[-1], f0
     return xopt.copy(), float(fopt)
+
+
+def fminsearch(fun, x0, tol_x=1e-4, tol_fun=1e-4, max_iter=None, max_fun_evals=None):
+    """Nelder-Mead simplex search with fminsearch's published constants and rules (Lagarias, Reeds, Wright & Wright,
+    SIAM J. Optim. 9 (1998); what GP/BayesOpt_v2b.m:44-46 and GP/BayesOptFcn_v1.m:55-57 call), one start, sequential.
+    Returns (x, f(x), exitflag, iterations, evaluations)."""
+    x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
+    n = x0.shape[0]
+    max_iter = 200 * n if max_iter is None else max_iter
+    max_fun_evals = 200 * n if max_fun_evals is None else max_fun_evals
+    rho, chi, psi, sigma = 1.0, 2.0, 0.5, 0.5
+    v = np.tile(x0[:, None], (1, n + 1))
+    for j in range(n):
+        v[j, j + 1] = 1.05 * x0[j] if x0[j] != 0 else 0.00025
+    fv = np.array([fun(v[:, j].copy()) for j in range(n + 1)])
+    order = np.argsort(fv, kind='stable')
+    fv, v = fv[order], v[:, order]
+    itercount, func_evals = 1, n + 1
+    while func_evals < max_fun_evals and itercount < max_iter:
+        if np.max(np.abs(fv[0] - fv[1:])) <= max(tol_fun, 10 * np.spacing(abs(fv[0]))) and \
+                np.max(np.abs(v[:, 1:] - v[:, :1])) <= max(tol_x, 10 * np.spacing(abs(np.max(v[:, 0])))):
+            break
+        xbar = np.sum(v[:, :n], axis=1) / n
+        xr = (1 + rho) * xbar - rho * v[:, -1]
+        fxr = fun(xr.copy())
+        func_evals += 1
+        shrink = False
+        if fxr < fv[0]:
+            xe = (1 + rho * chi) * xbar - rho * chi * v[:, -1]
+            fxe = fun(xe.copy())
+            func_evals += 1
+            if fxe < fxr:
+                v[:, -1], fv[-1] = xe, fxe
+            else:
+                v[:, -1], fv[-1] = xr, fxr
+        elif fxr < fv[n - 1]:
+            v[:, -1], fv[-1] = xr, fxr
+        elif fxr < fv[-1]:
+            xc = (1 + psi * rho) * xbar - psi * rho * v[:, -1]
+            fxc = fun(xc.copy())
+            func_evals += 1
+            if fxc <= fxr:
+                v[:, -1], fv[-1] = xc, fxc
+            else:
+                shrink = True
+        else:
+            xcc = (1 - psi) * xbar + psi * v[:, -1]
+            fxcc = fun(xcc.copy())
+            func_evals += 1
+            if fxcc < fv[-1]:
+                v[:, -1], fv[-1] = xcc, fxcc
+            else:
+                shrink = True
+        if shrink:
+            for j in range(1, n + 1):
+                v[:, j] = v[:, 0] + sigma * (v[:, j] - v[:, 0])
+                fv[j] = fun(v[:, j].copy())
+            func_evals += n
+        order = np.argsort(fv, kind='stable')
+        fv, v = fv[order], v[:, order]
+        itercount += 1
+    exitflag = 0 if (func_evals >= max_fun_evals or itercount >= max_iter) else 1
+    return v[:, 0].copy(), float(fv[0]), exitflag, itercount, func_evals
