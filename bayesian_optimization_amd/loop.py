@@ -70,3 +70,54 @@ def bayes_opt(x, y, xT, yT, sigmaY=0.0, kappa=0.01, ei_tol=1e-9, nruns=10, max_i
             break
     out['xT'], out['yT'] = xT, yT
     return out
+
+
+def bayes_opt_fcn_v1(fun, kappa, x0=None, maxit=20, sigmaY=0.0, paropt=None, verbose=0, rng=None, gp=None, device=0):
+    """The MATLAB scripts' BO loop as a function (GP/BayesOptFcn_v1.m:1-61), over a CONTINUOUS domain: per iteration the
+    length scales are refitted by cg_optim_wrap on (mlefun, jacmlefun) from x0 = 0.05 + 2.95 rand (:46-50), the next point
+    is fminsearch's minimiser of -acquisition_fcn(x) = -(Mu - kappa sqrt(diag(Cov))) from a uniform random start (:52-55;
+    single-factor posterior, :68-84), and the loop runs maxit + 1 times or until K stops being positive definite (:29-40).
+    fun: callable on a (d,) point.  paropt: dict with nruns, niter, alpha, beta, normalize, lb, ub (defaults :16-21).
+    rng: numpy Generator for the three kinds of random draws (MATLAB's generator cannot be reproduced).
+    Every numeric step runs on the device: the descent's likelihoods and gradients in lockstep over the nruns starts, the
+    posterior and the acquisition under the simplex search.  Returns (xT (k, d), yT (k, 1), theta_hist)."""
+    from . import acqopt
+    from .gp import GP
+    from .hyperopt import cg_optim_wrap
+    rng = np.random.default_rng() if rng is None else rng
+    x0 = rng.random(2) if x0 is None or np.size(x0) == 0 else np.asarray(x0, dtype=np.float64).reshape(-1)
+    d = x0.shape[0]
+    par = dict(nruns=200, niter=1000, alpha=0.01, beta=1, normalize=0, lb=None, ub=None)
+    par.update(paropt or {})
+    gp = gp or GP(device)
+    xT = x0[None, :].copy()
+    yT = np.array([[float(fun(x0))]])
+    theta_hist = []
+    i = 0
+    while i <= maxit:
+        if verbose:
+            print('Iteration-%d; FunEval = %4.2f' % (i, yT[-1, 0]))
+        th0 = (3 - 0.05) * rng.random(d) + 0.05
+        starts = rng.random((par['nruns'] - 1, d))
+        if par['lb'] is not None and np.size(par['lb']):
+            starts = (np.asarray(par['ub'], dtype=np.float64) - np.asarray(par['lb'], dtype=np.float64)) * starts + np.asarray(par['lb'], dtype=np.float64)
+        xstart = rng.random((1, d))
+        try:
+            theta, _ = cg_optim_wrap(xT, yT, sigmaY, th0, par['lb'], par['ub'], par['alpha'], par['beta'], par['nruns'], par['niter'],
+                                     par['normalize'], starts=starts, device=device)
+            theta_hist.append(np.array(theta, copy=True))
+            if np.all(np.isfinite(theta) & (theta != 0.0)):
+                gp.fit(xT, yT, theta, sigmaY, variant=L.VARIANT_SINGLE)
+                # maximise Mu - kappa sigma: the library's upper-confidence form with the sign of kappa turned
+                xs = acqopt.fminsearch(gp, xstart, L.ACQ_UCB, -float(kappa))[0][0]
+            else:
+                # the winning descent stopped early, so its last history row -- the returned theta -- is zero (with one training
+                # point the gradient is zero and every run stops at once): the kernel is then 0 away from the training points,
+                # the acquisition is flat, and fminsearch shrinks its simplex onto its starting vertex
+                xs = xstart[0]
+        except np.linalg.LinAlgError:
+            return xT, yT, theta_hist                # the positive-definiteness stop (:29-40; MATLAB's chol inside the descent errors instead)
+        xT = np.vstack([xT, xs[None, :]])
+        yT = np.vstack([yT, [[float(fun(xs))]]])
+        i += 1
+    return xT, yT, theta_hist

@@ -43,3 +43,18 @@ def test_fminsearch_on_the_device_acquisition_follows_the_cpu_restatement(gp0, d
         if abs(val[r] + fs) <= 1e-8 * max(1.0, abs(fs)) and np.max(np.abs(x[r] - xs)) <= 1e-5:
             same_optimum += 1
     assert same_optimum >= len(X0) - 1
+
+
+def test_matlab_loop_function_runs_on_the_device_and_finds_the_maximum():
+    """bayes_opt_fcn_v1 (GP/BayesOptFcn_v1.m:1-61): cg_optim_wrap for the length scales, fminsearch on the acquisition, append;
+    reduced descent settings so the test stays short.  The first iteration has ONE training point: the gradient of -logL is zero,
+    every descent stops at once and the returned theta is the zero row of its preallocated history (the reference's own
+    behaviour), so the first proposal is the random start itself; from the second iteration on the model steers."""
+    from bayesian_optimization_amd import loop
+    f = lambda x: float(np.exp(-8 * np.sum((np.asarray(x) - 0.6) ** 2)))
+    rng = np.random.default_rng(4)
+    xT, yT, th = loop.bayes_opt_fcn_v1(f, kappa=-2.0, x0=np.array([0.1, 0.2]), maxit=9, sigmaY=0.05,
+                                       paropt=dict(nruns=6, niter=80, alpha=0.02, beta=1, normalize=2), rng=rng)
+    assert xT.shape == (11, 2) and yT.shape == (11, 1) and len(th) == 10
+    assert np.all(th[0] == 0.0) and np.all(np.isfinite(np.array(th[1:]))) and np.all(np.array(th[2:]) != 0.0)
+    assert yT.max() > 0.8 and yT.max() > yT[0, 0] + 0.5           # kappa < 0 here: Mu + 2 sigma, an exploring rule that finds the bump
