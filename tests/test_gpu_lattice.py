@@ -185,3 +185,32 @@ def test_two_rank_lattice_loop_picks_the_same_points(gp0):
         jj, _, x = loop.step(x, float(f(x)), bo.ACQ_EI, 0.01)
     gp0.reserve_appends(0)
     assert res['config']['picked_head'] == picked[:16]
+
+
+def test_refit_with_other_length_scales_rebuilds_the_factor_tables():
+    """Lattice candidates stay resident across refits (same column count); the per-axis factor tables belong to a fit and are
+    rebuilt by the posterior that follows it: appends after a refit with other length scales, a larger training set and
+    another reserve equal the oracle on the enlarged set."""
+    from bayesian_optimization_amd import GP
+    axes = AXES[4]
+    grid = lattice(axes)
+    rng = np.random.default_rng(77)
+    gp = GP(0)
+    Xa = rng.random((7, 4))
+    for rnd, (theta, reserve, sY) in enumerate([(np.full(4, 0.3), 4, 1e-2), (np.array([0.5, 0.25, 0.4, 0.6]), 6, 0.05)]):
+        gp.reserve_appends(reserve)
+        gp.fit(Xa, objective(Xa), theta, sY, variant=bo.VARIANT_SINGLE)
+        if rnd == 0:
+            gp.set_candidates_lattice(axes)
+        mu_max = gp.posterior()
+        j, _ = gp.acquire(bo.ACQ_EI, 0.01, bo.INCUMBENT_GIVEN, mu_max)
+        for _ in range(reserve):
+            Xa = np.vstack([Xa, grid[j][None, :]])
+            mu_max, j, _ = gp.append_acquire(grid[j], float(objective(grid[j])), bo.ACQ_EI, 0.01, bo.INCUMBENT_MAX_MU)
+            assert gp.timings()['append_route'] == 1.0
+        mu, var = gp.read()
+        mu_o, var_o, _ = o.gprfcn_diag(grid, Xa, objective(Xa), theta, sY, variant=bo.VARIANT_SINGLE)
+        assert relmax(mu, mu_o) <= TOL_MU and relmax(var, var_o) <= TOL_VAR and mu_max == mu.max()
+        ei_o = o.expected_improvement(mu_o.copy(), var_o, 0.01)
+        assert j == int(np.argmax(ei_o))
+    gp.close()
