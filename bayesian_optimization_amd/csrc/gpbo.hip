@@ -460,12 +460,14 @@ int launch_trsv(gpbo_ctx* ctx, const double* L, double eps_val, const double* ep
     hipLaunchKernelGGL(k_refine_flag, dim3(1, 1, S), dim3(256), 0, ctx->stream, L, (long)ctx->n_pad, (int)ctx->n, ctx->params, ctx->bs);
     if (!ctx->no_timing) {
         // not under graph capture: read the flags back (one small copy) and skip the gated launches when no slot needs them
-        std::vector<double> flags(S, 0.0);
-        HIPCHK(hipMemcpy2DAsync(flags.data(), sizeof(double), ctx->params + P_REFINE, std::max<size_t>(ctx->bs.par, 1) * sizeof(double),
-                                sizeof(double), S, hipMemcpyDeviceToHost, ctx->stream));
+        // (one contiguous copy spanning the slots' parameter blocks: a strided hipMemcpy2DAsync to pageable memory left
+        // device memory allocated after the context was destroyed, one matrix's worth per context lifetime)
+        const size_t stride = S > 1 ? (size_t)ctx->bs.par : 1;
+        std::vector<double> flags((S - 1) * stride + 1, 0.0);
+        HIPCHK(hipMemcpyAsync(flags.data(), ctx->params + P_REFINE, flags.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         bool any = false;
-        for (double f : flags) any = any || f != 0.0;
+        for (unsigned sl = 0; sl < S; ++sl) any = any || flags[sl * stride] != 0.0;
         if (!any) return GPBO_OK;
     }
     for (int it = 0; it < steps; ++it) {
