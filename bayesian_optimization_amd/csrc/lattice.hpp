@@ -107,8 +107,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update(const d
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    gemm_tile_64x64<false>(A + (long)ib * QUARTER_M * lda, lda, B + (long)jb * 64, ldb, 0, kpad, acc, lds);
+    // The old sums of this tile are requested BEFORE the product, so that their HBM latency runs under it (-4.5 % on the
+    // kernel).  The old means are not: 16 more doubles per lane do not fit the 128 registers of four workgroups per CU
+    // (40 spilled, +20 % per update), and three workgroups per CU with both prefetched lose 3 % against this form.
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double s_old[2][4][2];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = (long)ib * 64 + (w >> 1) * 32 + ta * 16 + (lane >> 4) + 4 * r;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const long col = (long)jb * 64 + (w & 1) * 32 + tb * 16 + (lane & 15);
+                const bool in = row < P && col < Q;
+                const long j = in ? row * Q + col : 0;
+                s_old[ta][r][tb] = in ? sres[j] : 0.0;
+            }
+        }
+    gemm_tile_64x64<false>(A + (long)ib * QUARTER_M * lda, lda, B + (long)jb * 64, ldb, 0, kpad, acc, lds);
     const double znew = scal[A_ZNEW];
     double mx = -INFINITY;
 #pragma unroll
@@ -122,8 +139,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update(const d
                 if (row < P && col < Q) {
                     const long j = row * Q + col;
                     const double v = acc[ta][tb][r];
-                    const double s = sres[j] + v * v;
-                    sres[j] = s;
+                    sres[j] = s_old[ta][r][tb] + v * v;
                     const double mnew = mu[j] + v * znew;
                     mu[j] = mnew;
                     mx = max_nan(mx, mnew);
