@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 #include "lu.hpp"
 #include "lattice.hpp"
+#include "append_fused.hpp"
 
 #define GPBO_VARIANT_KRIGING 2      /* trend GP of Gaussian_Process_Regression.ipynb:197-234 (internal tag) */
 #define GPBO_VARIANT_KRIGING_LU 4   /* the same model solved through LU with partial pivoting: bufW holds P K = L U, ipiv the row exchanges */
@@ -770,23 +771,63 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new, bool defer_
     PointArg pa;
     for (int t = 0; t < MAX_D; ++t) pa.x[t] = (t < ctx->d) ? x_new[t] / ctx->theta[t] : 0.0;
     Scope tot(ctx, T_TOTAL);
-    hipLaunchKernelGGL(k_append_kvec, dim3((unsigned)((ctx->n_pad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xts, n,
-                       (int)ctx->n_pad, ctx->d, pa, ctx->xnew_dev, ctx->info_dev, ctx->kvec, ctx->kernel);
-    hipLaunchKernelGGL(k_append_lvec, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const double*)ctx->bufW, ld, n,
-                       (const double*)ctx->kvec, ctx->lvec);
-    hipLaunchKernelGGL(k_append_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->lvec, ctx->zfw, ctx->yv, n,
-                       y_new, ctx->eps, ctx->scal, ctx->params, ctx->bufL, ctx->bufW, ld, ctx->info_dev);
+    // small models: the chain of the factor update (and the lattice route's new table row) is one launch (append_fused.hpp);
+    // GPBO_APPEND_FUSED=0 keeps the separate launches
+    static const bool fused_on = !(getenv("GPBO_APPEND_FUSED") && atoi(getenv("GPBO_APPEND_FUSED")) == 0);
+    const bool fused = fused_on && n < APPEND_FUSED_MAX_N;
+    const long rows_elems = ctx->inc_lattice ? (long)std::max<int64_t>(ctx->lat_qpad, ctx->lat.split * ctx->lat_smax) : 0;
+    if (fused) {
+        AppendFusedArgs a{};
+        a.Xts = ctx->Xts;
+        a.n = n;
+        a.n_pad = (int)ctx->n_pad;
+        a.d = ctx->d;
+        a.kernel = ctx->kernel;
+        a.xnew_out = ctx->xnew_dev;
+        a.info = ctx->info_dev;
+        a.kvec = ctx->kvec;
+        a.lvec = ctx->lvec;
+        a.zfw = ctx->zfw;
+        a.yv = ctx->yv;
+        a.scal = ctx->scal;
+        a.params = ctx->params;
+        a.L = ctx->bufL;
+        a.W = ctx->bufW;
+        a.ld = ld;
+        a.y_new = y_new;
+        a.eps = ctx->eps;
+        a.with_wrow = ctx->inc_lattice ? 1 : 0;
+        a.alpha1 = ctx->alpha1;
+        a.alpha = ctx->alpha;
+        a.rows_elems = rows_elems;
+        a.axes = ctx->lat_axes;
+        a.E = ctx->latE;
+        a.B = ctx->latB;
+        a.kcap = (int)ctx->lat_kcap;
+        a.smax = (int)ctx->lat_smax;
+        a.ldb = (long)ctx->lat_qpad;
+        const unsigned extra = (unsigned)((rows_elems + APPEND_FUSED_THREADS - 1) / APPEND_FUSED_THREADS);
+        hipLaunchKernelGGL(k_append_fused, dim3(1 + extra), dim3(APPEND_FUSED_THREADS), 0, ctx->stream, a, pa, ctx->lat);
+    } else {
+        hipLaunchKernelGGL(k_append_kvec, dim3((unsigned)((ctx->n_pad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->Xts, n,
+                           (int)ctx->n_pad, ctx->d, pa, ctx->xnew_dev, ctx->info_dev, ctx->kvec, ctx->kernel);
+        hipLaunchKernelGGL(k_append_lvec, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, (const double*)ctx->bufW, ld, n,
+                           (const double*)ctx->kvec, ctx->lvec);
+        hipLaunchKernelGGL(k_append_scalars, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->lvec, ctx->zfw, ctx->yv, n,
+                           y_new, ctx->eps, ctx->scal, ctx->params, ctx->bufL, ctx->bufW, ld, ctx->info_dev);
+    }
     if (ctx->inc_lattice) {
         Scope sw(ctx, T_SWEEP);
         const int kpad = (int)round_up(n + 1, TK);
         const int tiles_q = (int)(ctx->lat_qpad / QUARTER_M);
         const long tiles = (long)(ctx->lat_ppad / QUARTER_M) * tiles_q;
-        hipLaunchKernelGGL(k_append_wrow, dim3((unsigned)((n + 1 + 31) / 32)), dim3(256), 0, ctx->stream, ctx->bufW, ld, n,
-                           (const double*)ctx->lvec, (const double*)ctx->scal, (const double*)ctx->zfw, ctx->alpha1, ctx->alpha);
-        hipLaunchKernelGGL(k_lattice_rows, dim3((unsigned)((std::max<int64_t>(ctx->lat_qpad, ctx->lat.split * ctx->lat_smax) + 255) / 256), 1u),
-                           dim3(256), 0, ctx->stream, ctx->lat, (const double*)ctx->lat_axes, (const double*)ctx->params,
-                           (const double*)ctx->Xts, (long)ctx->n_pad, n, ctx->latE, (int)ctx->lat_kcap, (int)ctx->lat_smax, ctx->latB,
-                           (long)ctx->lat_qpad);
+        if (!fused) {
+            hipLaunchKernelGGL(k_append_wrow, dim3((unsigned)((n + 1 + 31) / 32)), dim3(256), 0, ctx->stream, ctx->bufW, ld, n,
+                               (const double*)ctx->lvec, (const double*)ctx->scal, (const double*)ctx->zfw, ctx->alpha1, ctx->alpha);
+            hipLaunchKernelGGL(k_lattice_rows, dim3((unsigned)((rows_elems + 255) / 256), 1u), dim3(256), 0, ctx->stream, ctx->lat,
+                               (const double*)ctx->lat_axes, (const double*)ctx->params, (const double*)ctx->Xts, (long)ctx->n_pad, n,
+                               ctx->latE, (int)ctx->lat_kcap, (int)ctx->lat_smax, ctx->latB, (long)ctx->lat_qpad);
+        }
         hipLaunchKernelGGL(k_lattice_A, dim3((unsigned)((ctx->lat.P * kpad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->lat,
                            (const double*)ctx->latE, (int)ctx->lat_kcap, (int)ctx->lat_smax, (const double*)(ctx->bufW + (long)n * ld), n,
                            ctx->latA, (long)ctx->lat_kcap, kpad);

@@ -2431,10 +2431,9 @@ enum { A_DNEW = 0, A_ZNEW = 1, A_LL = 2, A_LZ = 3 };
 // kvec[i] = k(x_i, x_new) for i < n (0 for the pad); also records the new scaled point as column n of Xts.
 // First launch of a loop step: the new scaled point arrives as a kernel argument and is left in device memory (xnew_out)
 // for the kernels that follow, and the status word is cleared -- no launch, copy or fill of their own for either.
-__global__ __launch_bounds__(256) void k_append_kvec(double* __restrict__ Xts, int n, int n_pad, int d, PointArg p,
-                                                     double* __restrict__ xnew_out, int* __restrict__ info,
-                                                     double* __restrict__ kvec, int kernel) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void append_kvec_at(int i, double* __restrict__ Xts, int n, int n_pad, int d, const PointArg& p,
+                                               double* __restrict__ xnew_out, int* __restrict__ info, double* __restrict__ kvec,
+                                               int kernel) {
     if (i < MAX_D) xnew_out[i] = p.x[i];
     if (i == 0) *info = 0;
     if (i >= n_pad) return;
@@ -2452,11 +2451,15 @@ __global__ __launch_bounds__(256) void k_append_kvec(double* __restrict__ Xts, i
         for (int t = 0; t < d; ++t) Xts[(long)t * n_pad + n] = p.x[t];
 }
 
+__global__ __launch_bounds__(256) void k_append_kvec(double* __restrict__ Xts, int n, int n_pad, int d, PointArg p,
+                                                     double* __restrict__ xnew_out, int* __restrict__ info,
+                                                     double* __restrict__ kvec, int kernel) {
+    append_kvec_at(blockIdx.x * 256 + threadIdx.x, Xts, n, n_pad, d, p, xnew_out, info, kvec, kernel);
+}
+
 // l = W[0:n,0:n] * kvec  (one wave per row, lanes along the row)
-__global__ __launch_bounds__(256) void k_append_lvec(const double* __restrict__ W, long ld, int n, const double* __restrict__ kvec,
-                                                     double* __restrict__ lvec) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void append_lvec_row(int row, int lane, const double* __restrict__ W, long ld, int n,
+                                                const double* __restrict__ kvec, double* __restrict__ lvec) {
     if (row >= n) return;
     double s = 0.0;
     for (int j = lane; j <= row; j += 64) s += W[(long)row * ld + j] * kvec[j];
@@ -2464,31 +2467,36 @@ __global__ __launch_bounds__(256) void k_append_lvec(const double* __restrict__ 
     if (lane == 0) lvec[row] = s;
 }
 
+__global__ __launch_bounds__(256) void k_append_lvec(const double* __restrict__ W, long ld, int n, const double* __restrict__ kvec,
+                                                     double* __restrict__ lvec) {
+    append_lvec_row(blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, W, ld, n, kvec, lvec);
+}
+
 // One workgroup: d_new = sqrt(1 + eps - l.l), z_new = (y_new - l.z)/d_new, scalars of the enlarged model,
 // new rows of L (optional) and the diagonal of W.  n is the size BEFORE the append.
-__global__ __launch_bounds__(256) void k_append_scalars(const double* __restrict__ lvec, double* __restrict__ zfw,
-                                                        double* __restrict__ yv, int n, double y_new, double eps,
-                                                        double* __restrict__ scal, double* __restrict__ params,
-                                                        double* __restrict__ L, double* __restrict__ W, long ld,
-                                                        int* __restrict__ info) {
-    __shared__ double r1[256];
-    __shared__ double r2[256];
-    const int tid = threadIdx.x;
+// (tid < 256 and `active`: the 256 threads that do the work; every thread of the workgroup calls it, for the barriers)
+__device__ __forceinline__ void append_scalars_phase(int tid, bool active, double* r1, double* r2, const double* __restrict__ lvec,
+                                                     double* __restrict__ zfw, double* __restrict__ yv, int n, double y_new, double eps,
+                                                     double* __restrict__ scal, double* __restrict__ params, double* __restrict__ L,
+                                                     double* __restrict__ W, long ld, int* __restrict__ info) {
     double ll = 0.0, lz = 0.0;
-    for (int i = tid; i < n; i += 256) {
-        ll += lvec[i] * lvec[i];
-        lz += lvec[i] * zfw[i];
+    if (active) {
+        for (int i = tid; i < n; i += 256) {
+            ll += lvec[i] * lvec[i];
+            lz += lvec[i] * zfw[i];
+        }
+        r1[tid] = ll;
+        r2[tid] = lz;
     }
-    r1[tid] = ll;
-    r2[tid] = lz;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
+        if (active && tid < o) {
             r1[tid] += r1[tid + o];
             r2[tid] += r2[tid + o];
         }
         __syncthreads();
     }
+    if (!active) return;
     const double dd = 1.0 + eps - r1[0];
     const double dnew = sqrt(dd);
     const double znew = (y_new - r2[0]) / dnew;
@@ -2516,6 +2524,16 @@ __global__ __launch_bounds__(256) void k_append_scalars(const double* __restrict
         params[P_YMAX] = fmax(params[P_YMAX], y_new);
         params[P_NLL] = 0.5 * n1 * (log(2.0 * M_PI) + 1.0) + 0.5 * n1 * log(theta1) + sumlog;
     }
+}
+
+__global__ __launch_bounds__(256) void k_append_scalars(const double* __restrict__ lvec, double* __restrict__ zfw,
+                                                        double* __restrict__ yv, int n, double y_new, double eps,
+                                                        double* __restrict__ scal, double* __restrict__ params,
+                                                        double* __restrict__ L, double* __restrict__ W, long ld,
+                                                        int* __restrict__ info) {
+    __shared__ double r1[256];
+    __shared__ double r2[256];
+    append_scalars_phase(threadIdx.x, true, r1, r2, lvec, zfw, yv, n, y_new, eps, scal, params, L, W, ld, info);
 }
 
 // New row of W and the enlarged alpha, per column j <= n (n = size before the append):
@@ -2566,12 +2584,13 @@ __device__ __forceinline__ void append_wrow_alpha(int blk, double* __restrict__ 
 
 // The same update in a launch of its own (the lattice route of an append has no streaming sweep to ride along with): 32
 // columns x 8 threads per workgroup, thread q of a column forms partial sum q.
-__global__ __launch_bounds__(256) void k_append_wrow(double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
-                                                     const double* __restrict__ scal, const double* __restrict__ zfw,
-                                                     double* __restrict__ alpha1, double* __restrict__ alpha) {
-    __shared__ double ss[8][33], sa[8][33];
-    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + c;
+// (blk < 0: a thread group with no columns of its own, there for the barrier only)
+__device__ __forceinline__ void append_wrow_block(int blk, int t256, double (*ss)[33], double (*sa)[33], double* __restrict__ W, long ld,
+                                                  int n, const double* __restrict__ lvec, const double* __restrict__ scal,
+                                                  const double* __restrict__ zfw, double* __restrict__ alpha1,
+                                                  double* __restrict__ alpha) {
+    const int c = t256 & 31, q = t256 >> 5;
+    const int j = blk < 0 ? n + 1 : blk * 32 + c;
     double ps = 0.0, pa = 0.0;
     if (j < n) {
         for (int i = j + q; i < n; i += 8) {
@@ -2597,6 +2616,13 @@ __global__ __launch_bounds__(256) void k_append_wrow(double* __restrict__ W, lon
     a = fma(wn, zfw[n], a);
     alpha1[j] = a;
     alpha[j] = a;
+}
+
+__global__ __launch_bounds__(256) void k_append_wrow(double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
+                                                     const double* __restrict__ scal, const double* __restrict__ zfw,
+                                                     double* __restrict__ alpha1, double* __restrict__ alpha) {
+    __shared__ double ss[8][33], sa[8][33];
+    append_wrow_block((int)blockIdx.x, threadIdx.x, ss, sa, W, ld, n, lvec, scal, zfw, alpha1, alpha);
 }
 
 // The HBM-streaming sweep: per candidate j

@@ -36,19 +36,19 @@ __global__ __launch_bounds__(256) void k_lattice_points(LatticeDesc L, const dou
     }
 }
 
+// xts: the training point's coordinate on axis t, already divided by theta_t
 __device__ __forceinline__ double lattice_factor(const LatticeDesc& L, const double* __restrict__ axes, const double* __restrict__ params,
-                                                 const double* __restrict__ Xts, long n_pad, int t, int g, int i) {
-    const double df = axes[L.off[t] + g] * params[P_INVTHETA + t] - Xts[(long)t * n_pad + i];
+                                                 int t, int g, double xts) {
+    const double df = axes[L.off[t] + g] * params[P_INVTHETA + t] - xts;
     return exp(-0.5 * df * df);
 }
 
-// Rows i0 + blockIdx.y of the per-axis factor table of the prefix axes, E[(t * smax + g) * kcap + i], and of B (k-major:
-// B[i * ldb + q], columns q >= Q zero).  At the first posterior for all training points, afterwards one row per append.
-__global__ __launch_bounds__(256) void k_lattice_rows(LatticeDesc L, const double* __restrict__ axes, const double* __restrict__ params,
-                                                      const double* __restrict__ Xts, long n_pad, int i0, double* __restrict__ E,
-                                                      int kcap, int smax, double* __restrict__ B, long ldb) {
-    const int i = i0 + (int)blockIdx.y;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+// Row i of the per-axis factor table of the prefix axes, E[(t * smax + g) * kcap + i], and of B (k-major: B[i * ldb + q],
+// columns q >= Q zero), element idx of max(ldb, split * smax); x[t]: the scaled coordinates of training point i.
+template <typename XT>
+__device__ __forceinline__ void lattice_row_at(long idx, int i, const LatticeDesc& L, const double* __restrict__ axes,
+                                               const double* __restrict__ params, const XT& x, double* __restrict__ E, int kcap, int smax,
+                                               double* __restrict__ B, long ldb) {
     if (idx < ldb) {
         double v = 0.0;
         if (idx < L.Q) {
@@ -57,15 +57,24 @@ __global__ __launch_bounds__(256) void k_lattice_rows(LatticeDesc L, const doubl
             for (int t = L.d - 1; t >= L.split; --t) {
                 const int g = (int)(r % L.size[t]);
                 r /= L.size[t];
-                v *= lattice_factor(L, axes, params, Xts, n_pad, t, g, i);
+                v *= lattice_factor(L, axes, params, t, g, x(t));
             }
         }
         B[(long)i * ldb + idx] = v;
     }
     if (idx < (long)L.split * smax) {
         const int t = (int)(idx / smax), g = (int)(idx % smax);
-        if (g < L.size[t]) E[((long)t * smax + g) * kcap + i] = lattice_factor(L, axes, params, Xts, n_pad, t, g, i);
+        if (g < L.size[t]) E[((long)t * smax + g) * kcap + i] = lattice_factor(L, axes, params, t, g, x(t));
     }
+}
+
+// Rows i0 + blockIdx.y: at the first posterior for all training points, afterwards one row per append.
+__global__ __launch_bounds__(256) void k_lattice_rows(LatticeDesc L, const double* __restrict__ axes, const double* __restrict__ params,
+                                                      const double* __restrict__ Xts, long n_pad, int i0, double* __restrict__ E,
+                                                      int kcap, int smax, double* __restrict__ B, long ldb) {
+    const int i = i0 + (int)blockIdx.y;
+    auto x = [&](int t) { return Xts[(long)t * n_pad + i]; };
+    lattice_row_at((long)blockIdx.x * 256 + threadIdx.x, i, L, axes, params, x, E, kcap, smax, B, ldb);
 }
 
 // A[p][i] = W[n][i] prod_{t < split} e_t(i, g_t(p)) for i <= n, zero for n < i < kpad (row-major, i contiguous).

@@ -214,3 +214,14 @@ def test_refit_with_other_length_scales_rebuilds_the_factor_tables():
         ei_o = o.expected_improvement(mu_o.copy(), var_o, 0.01)
         assert j == int(np.argmax(ei_o))
     gp.close()
+
+
+def test_one_launch_factor_update_equals_the_separate_launches():
+    """Small models update the factor in one launch (chain of four phases in one workgroup, the lattice table row beside it);
+    GPBO_APPEND_FUSED=0 keeps one launch per link.  The same loops in two child processes: picks, theta1, -log L, mean and
+    variance bit for bit, on both routes, both kernels, and across the size limit of the one-launch form."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'check_fused_append.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'differing 0' in r.stdout
