@@ -45,7 +45,7 @@ __global__ __launch_bounds__(APPEND_FUSED_THREADS) void k_append_fused(AppendFus
     const int top = a.n_pad > MAX_D ? a.n_pad : MAX_D;
     for (int i = tid; i < top; i += APPEND_FUSED_THREADS) append_kvec_at(i, a.Xts, a.n, a.n_pad, a.d, p, a.xnew_out, a.info, a.kvec, a.kernel);
     __syncthreads();
-    for (int row = tid >> 6; row < a.n; row += APPEND_FUSED_THREADS / 64) append_lvec_row(row, tid & 63, a.W, a.ld, a.n, a.kvec, a.lvec);
+    for (int row0 = tid >> 6; row0 < a.n; row0 += 64) append_lvec_rows4(row0, tid & 63, a.W, a.ld, a.n, a.kvec, a.lvec);
     __syncthreads();
     append_scalars_phase(tid, tid < 256, r1, r2, a.lvec, a.zfw, a.yv, a.n, a.y_new, a.eps, a.scal, a.params, a.L, a.W, a.ld, a.info);
     if (!a.with_wrow) return;

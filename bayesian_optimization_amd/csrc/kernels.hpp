@@ -2467,6 +2467,34 @@ __device__ __forceinline__ void append_lvec_row(int row, int lane, const double*
     if (lane == 0) lvec[row] = s;
 }
 
+// Four rows (row0, row0 + 16, row0 + 32, row0 + 48) by one wave, their loads in flight together: for a single workgroup walking
+// over all rows the time is the number of memory round trips.  Each row's sum is formed exactly as in append_lvec_row.
+__device__ __forceinline__ void append_lvec_rows4(int row0, int lane, const double* __restrict__ W, long ld, int n,
+                                                  const double* __restrict__ kvec, double* __restrict__ lvec) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const int last = (row0 + 48 < n ? row0 + 48 : n - 1);
+    for (int j = lane; j <= last; j += 64) {
+        const double kj = kvec[j];
+        double wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + 16 * u;
+            wv[u] = (row < n && j <= row) ? W[(long)row * ld + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + 16 * u;
+            if (row < n && j <= row) s[u] += wv[u] * kj;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        double t = s[u];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0 && row0 + 16 * u < n) lvec[row0 + 16 * u] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_append_lvec(const double* __restrict__ W, long ld, int n, const double* __restrict__ kvec,
                                                      double* __restrict__ lvec) {
     append_lvec_row(blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, W, ld, n, kvec, lvec);
@@ -2593,7 +2621,18 @@ __device__ __forceinline__ void append_wrow_block(int blk, int t256, double (*ss
     const int j = blk < 0 ? n + 1 : blk * 32 + c;
     double ps = 0.0, pa = 0.0;
     if (j < n) {
-        for (int i = j + q; i < n; i += 8) {
+        int i = j + q;
+        for (; i + 24 < n; i += 32) {        // four loads in flight; the sums in the same order as one at a time
+            double w4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w4[u] = W[(long)(i + 8 * u) * ld + j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ps = fma(lvec[i + 8 * u], w4[u], ps);
+                pa = fma(w4[u], zfw[i + 8 * u], pa);
+            }
+        }
+        for (; i < n; i += 8) {
             const double w = W[(long)i * ld + j];
             ps = fma(lvec[i], w, ps);
             pa = fma(w, zfw[i], pa);
