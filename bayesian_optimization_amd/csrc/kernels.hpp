@@ -1,7 +1,8 @@
-// Device kernels of libgpbo (gfx950).  Everything is fp64.  Matrices are row-major,
-// padded to a multiple of 128 rows/columns (pad = identity), so no kernel needs edge
-// handling in the training dimension; candidate chunks are padded to 128 columns and
-// the padded columns are computed but never written to the outputs.
+// Device kernels of libgpbo (gfx950): the shared definitions are here, the kernels in the k_*.hpp parts included at the
+// end (covariance, Cholesky, inverse, triangular solves, posterior, acquisition, likelihood sweep, append).
+// Everything is fp64.  Matrices are row-major, padded to a multiple of 128 rows/columns (pad = identity), so no kernel
+// needs edge handling in the training dimension; candidate chunks are padded to 128 columns and the padded columns are
+// computed but never written to the outputs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -108,2764 +109,13 @@ __device__ __forceinline__ double kern_dfac(double D, int kernel) {
     return (5.0 / 3.0) * (1.0 + s5r) * exp(-s5r);
 }
 
-// ---------------------------------------------------------------------------------------
-// K(X,X): the 128-blocks on and below the block diagonal of the n_pad x n_pad matrix (all the factorisation reads; the
-// blocks above are never touched), scale*k(D) + eps on the diagonal, identity pad.
-// Xts is [d][n_pad] = X / theta.  scale_ptr == nullptr -> 1.  eps: eps_ptr[0] if eps_ptr, else eps_val.
-// A workgroup covers 32 rows x 64 columns; a thread owns one column j and KM_ROWS rows, so x_j[t] is loaded once per
-// KM_ROWS elements and the rows' coordinates are wave-uniform (scalar loads).
-constexpr int KM_ROWS = 8;
-__global__ __launch_bounds__(256) void k_kernel_matrix(const double* __restrict__ Xts, int n, int n_pad, int d,
-                                                       double* __restrict__ K, const double* __restrict__ scale_ptr,
-                                                       double eps_val, const double* __restrict__ eps_ptr, int kernel,
-                                                       BatchStride bs) {
-    if ((blockIdx.x * 64) / PB > (blockIdx.y * 32) / PB) return;      // strictly above the block diagonal
-    Xts += blockIdx.z * bs.xts;
-    K += blockIdx.z * bs.mat;
-    if (scale_ptr) scale_ptr += blockIdx.z * bs.par;
-    if (eps_ptr) eps_ptr += blockIdx.z * bs.slot;
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int i0 = blockIdx.y * 32 + (threadIdx.x >> 6) * KM_ROWS;      // n_pad is a multiple of 128: no ragged edge
-    const double scale = scale_ptr ? *scale_ptr : 1.0;
-    const double eps = eps_ptr ? *eps_ptr : eps_val;      // from device memory when the launch is replayed from a graph
-    double D[KM_ROWS];
-#pragma unroll
-    for (int r = 0; r < KM_ROWS; ++r) D[r] = 0.0;
-    for (int t = 0; t < d; ++t) {
-        const double xj = Xts[(long)t * n_pad + j];
-        const double* xi = Xts + (long)t * n_pad + i0;
-#pragma unroll
-        for (int r = 0; r < KM_ROWS; ++r) {
-            const double df = xi[r] - xj;
-            D[r] += df * df;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < KM_ROWS; ++r) {
-        const int i = i0 + r;
-        double v;
-        if (i == j) v = (i < n) ? scale + eps : 1.0;
-        else if (i < n && j < n) v = scale * kern_eval(D[r], kernel);
-        else v = 0.0;
-        K[(long)i * n_pad + j] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-
-// Diagonal block p of the blocked factorisation: Cholesky factor of the 128x128 block and its inverse in one
-// workgroup (1024 threads), both on a packed copy of the lower triangle in LDS (row r starts at r (r + 1) / 2), on the
-// MFMA routines below (potrf128_mfma / trinv128_mfma), which the one-workgroup likelihood kernel uses as well.
-// Writes L (lower, zeros above) back into A and inv(L) (lower, zeros above) into Dinv.
-// info: first failing 1-based global row (pivot <= 0 or NaN), set once.
-constexpr int POTRF_THREADS = 256;      // workgroup of the one-workgroup likelihood / descent routines for small n
-__device__ __forceinline__ constexpr int tri_off(int r) { return r * (r + 1) / 2; }
-constexpr int POTRF_LDS_PACKED = PB * (PB + 1) / 2;     // 8256 doubles
-#ifdef GPBO_STAMPS
-__device__ long long g_stamps[64];
-#define GPBO_STAMP(i, acc) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); if (acc) g_stamps[i] += t_ - g_stamps[63]; g_stamps[63] = t_; } } while (0)
-#else
-#define GPBO_STAMP(i, acc) do { } while (0)
-#endif
-constexpr int TRINV_T_DOUBLES = 64 * 65;
-
-// ---------------------------------------------------------------------------------------
-// MFMA form of the diagonal block (potrf128_mfma + trinv128_mfma): the block lives packed in LDS as before, but
-//   * a 16x16 diagonal tile is factored AND inverted by one wave entirely in registers: lane i < 16 holds row i, the pivot
-//     and the multipliers of other rows arrive through v_readlane (uniform, no LDS round trip, no barrier inside);
-//     its inverse is built column-wise (lane c holds column c) from the same registers;
-//   * the rows below a tile are multiplied by that inverse, and the trailing triangle is updated, on v_mfma_f64_16x16x4;
-//   * the inverse of the whole block is assembled from the eight tile inverses by recursive doubling on MFMA.
-// Fragment conventions of v_mfma_f64_16x16x4 (as in gemm_f64.hpp): operand A: lane l holds A[l & 15][l >> 4],
-// operand B: B[l >> 4][l & 15], result: element r of lane l is D[(l >> 4) + 4 r][l & 15].
-__device__ __forceinline__ double readlane_f64(double x, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-    return __hiloint2double(hi, lo);
-}
-
-constexpr int LEAF_P = 17;                        // pitch of a 16x16 tile inverse in LDS
-constexpr int LEAF_DOUBLES = 16 * LEAF_P;
-
-// Wave-level: Cholesky factor of the 16x16 tile at (c0, c0) of the packed block M, written back in place, and its
-// inverse into Wi[r * LEAF_P + c].  Returns the first failing column (pivot <= 0 or NaN) or -1.
-// The elimination runs on the 32x16 matrix [A; I]: lanes 0..15 hold the rows of A, lanes 16..31 the rows of the identity.
-// A row below the diagonal tile leaves an elimination as row * inv(L)^T, so lane 16 + m ends with row m of inv(L)^T,
-// i.e. column m of the inverse, from the very instructions that factor A.  Lanes >= 32 idle along.
-__device__ __forceinline__ int leaf_potrf_inv(double* __restrict__ M, int c0, double* __restrict__ Wi) {
-    const int lane = threadIdx.x & 63;
-    int i = lane & 31;                             // row of [A; I]
-    // opaque per call: otherwise the 32 lane masks (i > j, i == j) are hoisted out of the caller's loop over the tiles,
-    // do not fit the scalar registers and come back through v_readlane from a spill register inside the pivot chain
-    asm volatile("" : "+v"(i));
-    double v[16];
-    {
-        // all sixteen reads are issued before the first is used (every lane reads a valid address; the empty asm keeps
-        // the compiler from sinking the reads into the selects below, which would serialise sixteen LDS round trips)
-        const int r = i & 15;
-        const double* row = M + tri_off(c0 + r) + c0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = row[c <= r ? c : r];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) asm volatile("" : "+v"(v[c]));
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = (i < 16) ? ((c <= i) ? v[c] : 0.0) : ((c == i - 16) ? 1.0 : 0.0);
-    }
-    int fail = -1;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double piv = readlane_f64(v[j], j);
-        if (!(piv > 0.0) && fail < 0) fail = c0 + j;
-        // 1/sqrt from the hardware estimate and two Newton steps, sqrt as piv * (1/sqrt) with one correction
-        double rd = __builtin_amdgcn_rsq(piv);
-        rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
-        rd = rd * fma(-0.5 * piv * rd, rd, 1.5);
-        double d = piv * rd;
-        d = fma(0.5 * rd, fma(-d, d, piv), d);
-        const double lij = (i > j) ? v[j] * rd : 0.0;
-        v[j] = (i == j) ? d : lij;                 // rows above the diagonal hold zero in this column
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-            const double lcj = readlane_f64(v[j], c);          // L[c][j], uniform
-            v[c] = fma(-lij, lcj, v[c]);           // entries right of a row's diagonal pick up values nobody reads
-        }
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c <= i) M[tri_off(c0 + i) + c0 + c] = v[c];
-    } else if (lane < 32) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Wi[r * LEAF_P + (i - 16)] = v[r];
-    }
-    return fail;
-}
-
-// Factor of the packed 128x128 block M in place; Wi8: [8][LEAF_DOUBLES] receives the inverses of the eight diagonal tiles.
-// Per 16-column panel: the rows below the diagonal tile are multiplied by its inverse, then the trailing triangle is
-// updated.  The next diagonal tile is updated first, by wave 0, which goes on to factor it while the other waves
-// update the rest of the triangle: the tile factorisation (one wave, a chain of 16 pivots) is the critical path, and
-// this way only the small row-scaling phase stands between two of them.  All threads must call it; ends on a barrier.
-// ntl: number of leading 16x16 tile rows that hold data; from there on the block must be the identity pad (zero off the
-// diagonal, one on it), which is left as it is and whose tile inverses are set to the identity.
-__device__ __forceinline__ void potrf128_mfma(double* __restrict__ M, double* __restrict__ Wi8, int* __restrict__ failp,
-                                              int ntl = 8) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    for (int idx = tid; idx < (8 - ntl) * 256; idx += blockDim.x) {
-        const int b = ntl + (idx >> 8), r = (idx >> 4) & 15, c = idx & 15;
-        Wi8[b * LEAF_DOUBLES + r * LEAF_P + c] = (r == c) ? 1.0 : 0.0;
-    }
-    auto leaf = [&](int jb) {
-        const int fail = leaf_potrf_inv(M, 16 * jb, Wi8 + jb * LEAF_DOUBLES);
-        if (lane == 0 && fail >= 0 && *failp < 0) *failp = fail;
-    };
-    GPBO_STAMP(0, 0);
-    if (w == 0) leaf(0);
-    GPBO_STAMP(1, 1);
-    __syncthreads();
-    for (int jb = 0; jb < ntl - 1; ++jb) {
-        const int c0 = 16 * jb;
-        const double* Wi = Wi8 + jb * LEAF_DOUBLES;
-        const int nt = ntl - 1 - jb;                 // 16-row tiles below the diagonal tile (the pad has zeros there)
-        GPBO_STAMP(0, 0);
-        // rows below: X = A[rows, c0:c0+16] * inv(L11)^T, one tile per wave and turn
-        for (int t = w; t < nt; t += nw) {
-            const int r0 = c0 + 16 + 16 * t;
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double a = M[tri_off(r0 + li) + c0 + 4 * q + lk];
-                const double b = Wi[li * LEAF_P + 4 * q + lk];          // B[k][j] = inv(L11)[j][k]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) M[tri_off(r0 + lk + 4 * r) + c0 + li] = acc[r];
-        }
-        __syncthreads();
-        GPBO_STAMP(2, 1);
-        // trailing triangle: A[I, J] -= X_I X_J^T over the tile pairs I >= J; pair 0 is the next diagonal tile
-        // With more than four waves, those that share wave 0's SIMD (w = 4, 8, ...) sit this phase out: the tile
-        // factorisation is a chain of dependent instructions and runs faster with its SIMD to itself.
-        const int npair = nt * (nt + 1) / 2;
-        const bool spare = nw > 4;
-        const int helpers = spare ? nw - nw / 4 : nw - 1;                // waves working on pairs 1 ..
-        const int hidx = spare ? w - 1 - w / 4 : w - 1;                  // this wave's index among them
-        const bool idle = spare && w != 0 && (w & 3) == 0;
-        const int first = (w == 0) ? 0 : (idle ? npair : 1 + hidx), step = helpers > 0 ? helpers : 1;
-        for (int pr = first; pr < npair; pr = (pr == 0 && nw > 1) ? npair : pr + step) {
-            int ti, tj;
-            tri_decode(pr, ti, tj);
-            const int rI = c0 + 16 + 16 * ti, rJ = c0 + 16 + 16 * tj;
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double a = M[tri_off(rI + li) + c0 + 4 * q + lk];
-                const double b = M[tri_off(rJ + li) + c0 + 4 * q + lk];  // B[k][j] = X_J[j][k]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rI + lk + 4 * r, col = rJ + li;
-                if (col <= row) M[tri_off(row) + col] -= acc[r];
-            }
-        }
-        if (w == 0) {
-            // the tile this wave just updated is read back by the same wave: LDS serves a wave's requests in order
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            GPBO_STAMP(0, 0);
-            leaf(jb + 1);
-            GPBO_STAMP(1, 1);
-        }
-        __syncthreads();
-        GPBO_STAMP(3, 1);
-    }
-}
-
-// One level of the block inverse on MFMA.  Before: the diagonal blocks of size S hold their inverses, the blocks below
-// them still hold L.  Pair p joins A = [2pS, 2pS+S) and B = A + S:  W[B,A] = -W[B,B] (L[B,A] W[A,A]).
-// ntl: tile rows from ntl on are the identity pad (see potrf128_mfma): their rows of W[B,A] are zero and stay untouched.
-template <int S>
-__device__ __forceinline__ void trinv_level_mfma(double* __restrict__ M, double* __restrict__ T, int ntl) {
-    constexpr int P = PB / (2 * S), NT = S / 16, TP = S + 1;
-    constexpr int TILES = P * NT * NT;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    for (int t = w; t < TILES; t += nw) {            // T = L[B,A] W[A,A]; W[A,A] lower: k-tiles kt >= jt
-        const int p = t / (NT * NT), it = (t / NT) % NT, jt = t % NT;
-        const int a0 = 2 * p * S, b0 = a0 + S;
-        if (b0 + 16 * it >= 16 * ntl) continue;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kt = jt; kt < NT; ++kt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = 16 * kt + 4 * q + lk, j = 16 * jt + li;
-                const double a = M[tri_off(b0 + 16 * it + li) + a0 + k];
-                const double bv = M[tri_off(a0 + k) + a0 + (j <= k ? j : k)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (j <= k) ? bv : 0.0, acc, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[p * S * TP + (16 * it + lk + 4 * r) * TP + 16 * jt + li] = acc[r];
-    }
-    __syncthreads();
-    for (int t = w; t < TILES; t += nw) {            // W[B,A] = -W[B,B] T; W[B,B] lower: k-tiles kt <= it
-        const int p = t / (NT * NT), it = (t / NT) % NT, jt = t % NT;
-        const int a0 = 2 * p * S, b0 = a0 + S;
-        if (b0 + 16 * it >= 16 * ntl) continue;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kt = 0; kt <= it; ++kt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = 16 * kt + 4 * q + lk, i = 16 * it + li;
-                const double av = M[tri_off(b0 + i) + b0 + (k <= i ? k : i)];
-                const double b = T[p * S * TP + k * TP + 16 * jt + li];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((k <= i) ? av : 0.0, b, acc, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) M[tri_off(b0 + 16 * it + lk + 4 * r) + a0 + 16 * jt + li] = -acc[r];
-    }
-    __syncthreads();
-}
-
-// Inverse of the packed lower-triangular block M in place, given the inverses of its eight diagonal tiles.
-// T: 64 * 65 doubles.  All 256 threads; ends on a barrier.
-__device__ __forceinline__ void trinv128_mfma(double* __restrict__ M, const double* __restrict__ Wi8, double* __restrict__ T,
-                                              int ntl = 8) {
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < 8 * 256; idx += blockDim.x) {      // tile inverses into the diagonal tiles
-        const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
-        if (c <= r) M[tri_off(16 * b + r) + 16 * b + c] = Wi8[b * LEAF_DOUBLES + r * LEAF_P + c];
-    }
-    __syncthreads();
-    trinv_level_mfma<16>(M, T, ntl);
-    trinv_level_mfma<32>(M, T, ntl);
-    trinv_level_mfma<64>(M, T, ntl);
-}
-
-// 16-row tiles of diagonal block p that hold data when the matrix has n real rows (the rest of the block, padding up to
-// a multiple of 128, is the identity and is skipped by the MFMA routines)
-__device__ __forceinline__ int data_tiles(int n, int p) {
-    const int t = (n - p * PB + 15) >> 4;
-    return t < 1 ? 1 : (t > 8 ? 8 : t);
-}
-
-// defer: stop after the factor; the inverses of the eight 16x16 diagonal tiles go into the diagonal
-// tiles of the block's Dinv (all k_trsm_rows needs), the inverse of the whole block is left to k_trinv_diag.
-__device__ __forceinline__ void potrf_diag_body(double* __restrict__ A, long ld, int p, double* __restrict__ Dinv,
-                                                int* __restrict__ info, double* __restrict__ S, bool defer, int ntl) {
-    __shared__ int fail_s;
-    const int tid = threadIdx.x;
-    double* blk = A + (long)p * PB * ld + (long)p * PB;
-    double* Tbuf = S + POTRF_LDS_PACKED;
-    double* Wi8 = Tbuf + TRINV_T_DOUBLES;
-    GPBO_STAMP(8, 0);
-    if (tid == 0) fail_s = -1;
-    // lower triangle -> packed LDS.  Eight requests per thread go out before the first is waited for (with 1024 threads
-    // that is the whole block in one memory round trip; a load inside the "c <= r" branch is waited for where it is
-    // issued, eight round trips in a row on the factorisation's critical path).  The pairs right of the diagonal are
-    // read as well (they lie inside the block) and dropped.
-    for (int base = 0; base < PB * PB / 2; base += 8 * (int)blockDim.x) {
-        f64x2 v[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = base + it * (int)blockDim.x + tid;
-            const int ii = idx < PB * PB / 2 ? idx : PB * PB / 2 - 1;
-            v[it] = *reinterpret_cast<const f64x2*>(blk + (long)(ii >> 6) * ld + (ii & 63) * 2);
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = base + it * (int)blockDim.x + tid;
-            const int r = idx >> 6, c = (idx & 63) * 2;
-            if (idx < PB * PB / 2 && c <= r) {
-                S[tri_off(r) + c] = v[it].x;
-                if (c + 1 <= r) S[tri_off(r) + c + 1] = v[it].y;
-            }
-        }
-    }
-    __syncthreads();
-    GPBO_STAMP(4, 1);
-    potrf128_mfma(S, Wi8, &fail_s, ntl);
-    GPBO_STAMP(5, 1);
-    if (tid == 0 && fail_s >= 0) atomicCAS(info, 0, p * PB + fail_s + 1);
-    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {      // L -> global, zeros above the diagonal
-        const int r = idx >> 6, c = (idx & 63) * 2;
-        f64x2 v;
-        v.x = (c <= r) ? S[tri_off(r) + c] : 0.0;
-        v.y = (c + 1 <= r) ? S[tri_off(r) + c + 1] : 0.0;
-        *reinterpret_cast<f64x2*>(blk + (long)r * ld + c) = v;
-    }
-    double* dinv = Dinv + (long)p * PB * PB;
-    if (defer) {
-        for (int idx = tid; idx < 8 * 256; idx += blockDim.x) {
-            const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
-            dinv[(16 * b + r) * PB + 16 * b + c] = (c <= r) ? Wi8[b * LEAF_DOUBLES + r * LEAF_P + c] : 0.0;
-        }
-        GPBO_STAMP(6, 1);
-        return;
-    }
-    __syncthreads();
-    GPBO_STAMP(6, 1);
-    trinv128_mfma(S, Wi8, Tbuf, ntl);
-    GPBO_STAMP(7, 1);
-    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
-        const int r = idx >> 6, c = (idx & 63) * 2;
-        f64x2 v;
-        v.x = (c <= r) ? S[tri_off(r) + c] : 0.0;
-        v.y = (c + 1 <= r) ? S[tri_off(r) + c + 1] : 0.0;
-        *reinterpret_cast<f64x2*>(dinv + r * PB + c) = v;
-    }
-    GPBO_STAMP(9, 1);
-}
-
-// The LDS request (packed L, the product buffer of the inverse and the tile inverses: 116 KB) keeps every
-// tile-engine workgroup (72 KB of 160) off the CU: the kernel is latency bound and runs 4x slower when its waves share
-// SIMDs with MFMA waves.
-constexpr int POTRF_MFMA_THREADS = 1024;        // 16 waves: the MFMA phases are LDS-latency bound, four waves per SIMD hide it
-__global__ __launch_bounds__(POTRF_MFMA_THREADS) void k_potrf_diag(double* __restrict__ A, long ld, int p,
-                                                              double* __restrict__ Dinv, int* __restrict__ info, BatchStride bs,
-                                                              int defer, int n) {
-    __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES];
-    potrf_diag_body(A + blockIdx.z * bs.mat, ld, p, Dinv + blockIdx.z * bs.dinv, info + blockIdx.z * bs.slot * 2, S, defer != 0,
-                    data_tiles(n, p));
-}
-
-// Panel solve: rows below diagonal block p, in place:  A[ib, p] <- A[ib, p] * inv(L_pp)^T
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_panel(double* __restrict__ A, long ld, int p,
-                                                             const double* __restrict__ Dinv, BatchStride bs) {
-    __shared__ double lds[GEMM_LDS_DOUBLES];
-    A += blockIdx.z * bs.mat;
-    Dinv += blockIdx.z * bs.dinv;
-    __builtin_amdgcn_s_setprio(2);
-    const int ib = p + 1 + blockIdx.x;
-    double* Ap = A + (long)ib * PB * ld + (long)p * PB;
-    f64x4 acc[4][4];
-    acc_zero(acc);
-    // (k,j) of the B operand = inv(L)[j][k]  -> k contiguous, ld 128
-    gemm_tile_128<true, true>(Ap, ld, Dinv + (long)p * PB * PB, PB, 0, PB, acc, lds);
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ap[(long)acc_row(ta, r) * ld + acc_col(tb)] = acc[ta][tb][r];
-}
-
-// Panel solve without LDS, one wave per 16 rows of the panel: X L_pp^T = A[rows, p], solved as L_pp X^T = A^T by block
-// forward substitution over the eight 16x16 tiles of L_pp,
-//   X^T_j = inv(L_jj) (A^T_j - sum_{k<j} L_jk X^T_k),
-// every operand fragment read straight from global memory (L2) into registers, all reads of a wave in flight at once.
-// The 128-tile engine pays one memory round trip per 16 k-values, eight in a row at K = 128, and the panel solve sits on
-// the factorisation's critical path with at most nb - 1 workgroups; here eight times as many SIMDs work, nothing waits
-// on LDS or barriers, and only the inverses of the 16x16 diagonal tiles are needed (the diagonal tiles of Dinv), so the
-// inverse of the whole block can be formed off the critical path.
-// v_mfma_f64_16x16x4: A operand lane l = A[l & 15][kk], B operand = B[kk][l & 15], kk = l >> 4; result element r of lane
-// l = D[(l >> 4) + 4 r][l & 15].  A result feeds the next product as B operand without leaving its registers: in
-// sub-step r lane l offers row (l >> 4) + 4 r, so the A operand of that sub-step is read at k = (l >> 4) + 4 r (the
-// order of the k-sum is free).  The tiles are kept negated (nx = -X^T) so that the sum accumulates onto A^T.
-__global__ __launch_bounds__(64) void k_trsm_rows(double* __restrict__ A, long ld, int p, const double* __restrict__ Dinv,
-                                                 BatchStride bs) {
-    A += blockIdx.z * bs.mat;
-    const double* Wd = Dinv + blockIdx.z * bs.dinv + (long)p * PB * PB;
-    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
-    const double* Lb = A + (long)p * PB * ld + (long)p * PB;
-    double* rows = A + ((long)(p + 1) * PB + 16 * (long)blockIdx.x) * ld + (long)p * PB;
-    f64x4 st[8];                                   // A^T tiles: element r = A[row li][16 j + lk + 4 r]
-    double lf[28][4], wf[8][4];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            st[j][r] = rows[(long)li * ld + 16 * j + lk + 4 * r];
-            wf[j][r] = Wd[(16 * j + li) * PB + 16 * j + lk + 4 * r];
-        }
-#pragma unroll
-    for (int j = 1; j < 8; ++j)
-#pragma unroll
-        for (int k = 0; k < j; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lf[j * (j - 1) / 2 + k][r] = Lb[(long)(16 * j + li) * ld + 16 * k + lk + 4 * r];
-    f64x4 x[8], nx[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        f64x4 sacc = st[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(lf[j * (j - 1) / 2 + k][r], nx[k][r], sacc, 0, 0, 0);
-        f64x4 xa = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xa = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[j][r], sacc[r], xa, 0, 0, 0);
-        x[j] = xa;
-        nx[j] = -xa;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rows[(long)li * ld + 16 * j + lk + 4 * r] = x[j][r];
-}
-
-// Inverse of factored diagonal blocks p0 + blockIdx.x, from L (in A) and the tile inverses (diagonal tiles of Dinv),
-// for the blocks whose factorisation kernel left it out (it is not needed by k_trsm_rows).
-__global__ __launch_bounds__(1024) void k_trinv_diag(const double* __restrict__ A, long ld, int p0, double* __restrict__ Dinv,
-                                                    BatchStride bs, int n) {
-    __shared__ double S[POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES];
-    const int tid = threadIdx.x, p = p0 + blockIdx.x;
-    const double* blk = A + blockIdx.z * bs.mat + (long)p * PB * ld + (long)p * PB;
-    double* dinv = Dinv + blockIdx.z * bs.dinv + (long)p * PB * PB;
-    double* Tbuf = S + POTRF_LDS_PACKED;
-    double* Wi8 = Tbuf + TRINV_T_DOUBLES;
-    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
-        const int r = idx >> 6, c = (idx & 63) * 2;
-        if (c <= r) {
-            const f64x2 v = *reinterpret_cast<const f64x2*>(blk + (long)r * ld + c);
-            S[tri_off(r) + c] = v.x;
-            if (c + 1 <= r) S[tri_off(r) + c + 1] = v.y;
-        }
-    }
-    for (int idx = tid; idx < 8 * 256; idx += blockDim.x) {
-        const int b = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
-        Wi8[b * LEAF_DOUBLES + r * LEAF_P + c] = dinv[(16 * b + r) * PB + 16 * b + c];
-    }
-    __syncthreads();
-    trinv128_mfma(S, Wi8, Tbuf, data_tiles(n, p));
-    for (int idx = tid; idx < PB * PB / 2; idx += blockDim.x) {
-        const int r = idx >> 6, c = (idx & 63) * 2;
-        f64x2 v;
-        v.x = (c <= r) ? S[tri_off(r) + c] : 0.0;
-        v.y = (c + 1 <= r) ? S[tri_off(r) + c + 1] : 0.0;
-        *reinterpret_cast<f64x2*>(dinv + r * PB + c) = v;
-    }
-}
-
-// Trailing update with a group of solved panels: A[ib, jb] -= P[ib] * P[jb]^T,
-// P[x] = A[x, kcol0 : kcol0 + klen] (klen = 128 .. 512: several adjacent panels at once, so the
-// read-modify-write of a tile of A is paid once per group instead of once per panel).
-// TRI: 1-D grid over the lower tiles of the square of blocks starting at b0 (ib = b0 + i, jb = b0 + j, j <= i).
-// !TRI: a rectangle of blocks, ib = b0 + blockIdx.y, jb = jb0 + blockIdx.x (every tile is computed).
-template <bool TRI, int MODE = 1, int BAND = 0>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(double* __restrict__ A, long ld, int b0, int jb0, int kcol0,
-                                                              int klen, BatchStride bs) {
-    A += blockIdx.z * bs.mat;
-    int ib, jb;
-    if (TRI) {
-        int i, j;
-        if constexpr (BAND > 0)
-            band_decode<BAND>(blockIdx.x, jb0, i, j);       // jb0 carries the number of block rows here
-        else
-            tri_decode(blockIdx.x, i, j);
-        ib = b0 + i;
-        jb = b0 + j;
-    } else {
-        ib = b0 + blockIdx.y;
-        jb = jb0 + blockIdx.x;
-        __builtin_amdgcn_s_setprio(2);       // the rectangular form is only used on the factorisation's critical path
-    }
-    __shared__ double lds[GEMM_LDS_DOUBLES];
-    const double* Pi = A + (long)ib * PB * ld + kcol0;
-    const double* Pj = A + (long)jb * PB * ld + kcol0;
-    // The accumulators start at -C and the tile is stored as -(acc): the read of C then travels with the first operand
-    // loads instead of standing as a second memory round trip after the product (sign flips are exact).
-    f64x4 acc[4][4];
-    double* C = A + (long)ib * PB * ld + (long)jb * PB;
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)acc_row(ta, r) * ld + acc_col(tb)];
-    gemm_tile_128<true, true, MODE>(Pi, ld, Pj, ld, 0, klen, acc, lds);
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = -acc[ta][tb][r];
-}
-
-// The same update on 64 x 128 half tiles (gemm_tile_64x128), for launches whose 128 x 128 tiles would leave most of the
-// chip idle: twice the workgroups, each with half the MFMA time.  Grid: 2 x the tiles of k_syrk_update, blockIdx.x =
-// 2 * tile + half (TRI) or blockIdx.x = 2 * column + half, blockIdx.y = row (!TRI).
-template <bool TRI>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update_half(double* __restrict__ A, long ld, int b0, int jb0, int kcol0,
-                                                                   int klen, BatchStride bs) {
-    A += blockIdx.z * bs.mat;
-    const int h = blockIdx.x & 1;
-    int ib, jb;
-    if (TRI) {
-        int i, j;
-        tri_decode(blockIdx.x >> 1, i, j);
-        ib = b0 + i;
-        jb = b0 + j;
-    } else {
-        ib = b0 + blockIdx.y;
-        jb = jb0 + (blockIdx.x >> 1);
-        __builtin_amdgcn_s_setprio(2);
-    }
-    __shared__ double lds[HALF_LDS_DOUBLES];
-    const double* Pi = A + ((long)ib * PB + h * HALF_M) * ld + kcol0;
-    const double* Pj = A + (long)jb * PB * ld + kcol0;
-    double* C = A + ((long)ib * PB + h * HALF_M) * ld + (long)jb * PB;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 64 + (lane & 15);
-    f64x4 acc[2][4];            // start at -C, store -(acc): see k_syrk_update
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16];
-    gemm_tile_64x128<true>(Pi, ld, Pj, ld, 0, klen, acc, lds);
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
-}
-
-// The same update on 64 x 64 quarter tiles (gemm_tile_64x64), for launches with so few tiles that the half tiles still leave
-// CUs idle or double up on some: four workgroups per 128 x 128 tile, blockIdx.x = 4 * tile + 2 * (row half) + (column half),
-// over the lower tiles of the square of blocks starting at b0.
-// !TRI: a rectangle of blocks, ib = b0 + blockIdx.y, jb = jb0 + (blockIdx.x >> 2) (the updates inside a group of panels).
-template <bool TRI>
-__global__ __launch_bounds__(GEMM_THREADS, 4) void k_syrk_update_quarter(double* __restrict__ A, long ld, int b0, int jb0, int kcol0,
-                                                                         int klen, BatchStride bs) {
-    A += blockIdx.z * bs.mat;
-    const int hr = (blockIdx.x >> 1) & 1, hc = blockIdx.x & 1;
-    int ib, jb;
-    if (TRI) {
-        int i, j;
-        tri_decode(blockIdx.x >> 2, i, j);
-        ib = b0 + i;
-        jb = b0 + j;
-    } else {
-        ib = b0 + blockIdx.y;
-        jb = jb0 + (blockIdx.x >> 2);
-        __builtin_amdgcn_s_setprio(2);
-    }
-    __shared__ double lds[QUARTER_LDS_DOUBLES];
-    const double* Pi = A + ((long)ib * PB + hr * QUARTER_M) * ld + kcol0;
-    const double* Pj = A + ((long)jb * PB + hc * QUARTER_M) * ld + kcol0;
-    double* C = A + ((long)ib * PB + hr * QUARTER_M) * ld + (long)jb * PB + hc * QUARTER_M;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 32 + (lane & 15);
-    f64x4 acc[2][2];            // start at -C, store -(acc): see k_syrk_update
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ta][tb][r] = -C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16];
-    gemm_tile_64x64(Pi, ld, Pj, ld, 0, klen, acc, lds);
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
-}
-
-// Zero the strict upper triangle (the factorisation leaves stale values there).
-__global__ __launch_bounds__(256) void k_zero_upper(double* __restrict__ A, int n_pad, BatchStride bs) {
-    A += blockIdx.z * bs.mat;
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i < n_pad && j < n_pad && j > i) A[(long)i * n_pad + j] = 0.0;
-}
-
-// ---------------------------------------------------------------------------------------
-// Triangular inverse W = inv(L) by recursive doubling over 128-blocks.
-// Level with half-size sb (in blocks); pair q joins A = blocks [a0, a0+sb) and
-// B = blocks [b0, b0+rows) below it:  W[B,A] = -inv(L_BB) * L[B,A] * inv(L_AA).
-__global__ __launch_bounds__(256) void k_inv_copy_diag(double* __restrict__ W, long ld, const double* __restrict__ Dinv,
-                                                       BatchStride bs) {
-    W += blockIdx.z * bs.mat;
-    Dinv += blockIdx.z * bs.dinv;
-    const int p = blockIdx.x;
-    double* blk = W + (long)p * PB * ld + (long)p * PB;
-    const double* src = Dinv + (long)p * PB * PB;
-    // pairs of doubles, eight requests per thread in flight (one after the other the copy is a chain of 64 round trips)
-    for (int base = 0; base < PB * PB / 2; base += 8 * 256) {
-        f64x2 v[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const f64x2*>(src + 2 * (base + it * 256 + (int)threadIdx.x));
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = base + it * 256 + (int)threadIdx.x;
-            *reinterpret_cast<f64x2*>(blk + (long)(idx >> 6) * ld + (idx & 63) * 2) = v[it];
-        }
-    }
-}
-
-// step 1: T[B,A] = L[B,A] * W[A,A]      (W[A,A] lower triangular: k >= j)
-// HALF (both steps): 64 x 128 half tiles, blockIdx.x = 2 * (x index) + half, for the levels whose 128 x 128 tiles are too
-// few to fill the chip (see gemm_tile_64x128); same sums in the same order.
-template <bool HALF>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step1(const double* __restrict__ L, const double* __restrict__ W,
-                                                            double* __restrict__ T, long ld, int sb, int nb, BatchStride bs) {
-    const int pairs = (nb + 2 * sb - 1) / (2 * sb);      // gridDim.z = pairs * slots
-    const int q = blockIdx.z % pairs, slot = blockIdx.z / pairs;
-    L += slot * bs.mat;
-    W += slot * bs.mat;
-    T += slot * bs.mat;
-    const int a0 = 2 * q * sb, b0 = a0 + sb;
-    const int rows = min(sb, nb - b0);
-    const int ib = HALF ? blockIdx.x >> 1 : blockIdx.x, jb = blockIdx.y;      // jb slow: the long tiles (small jb) are dispatched first
-    if (ib >= rows) return;
-    if (HALF) {
-        __shared__ double ldh[HALF_LDS_DOUBLES];
-        const int h = blockIdx.x & 1;
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 64 + (lane & 15);
-        f64x4 acc[2][4];
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
-        const double* Ap = L + ((long)(b0 + ib) * PB + h * HALF_M) * ld + (long)a0 * PB;
-        const double* Bp = W + (long)a0 * PB * ld + (long)(a0 + jb) * PB;
-        gemm_tile_64x128<false>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, ldh);
-        double* C = T + ((long)(b0 + ib) * PB + h * HALF_M) * ld + (long)(a0 + jb) * PB;
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = acc[ta][tb][r];
-        return;
-    }
-    __shared__ double lds[GEMM_LDS_DOUBLES];
-    f64x4 acc[4][4];
-    acc_zero(acc);
-    const double* Ap = L + (long)(b0 + ib) * PB * ld + (long)a0 * PB;
-    const double* Bp = W + (long)a0 * PB * ld + (long)(a0 + jb) * PB;
-    gemm_tile_128<true, false, 0>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, lds);
-    double* C = T + (long)(b0 + ib) * PB * ld + (long)(a0 + jb) * PB;
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = acc[ta][tb][r];
-}
-
-// step 2: W[B,A] = - W[B,B] * T[B,A]    (W[B,B] lower triangular: k <= i)
-template <bool HALF>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_inv_step2(double* __restrict__ W, const double* __restrict__ T, long ld,
-                                                            int sb, int nb, BatchStride bs) {
-    const int pairs = (nb + 2 * sb - 1) / (2 * sb);
-    const int q = blockIdx.z % pairs, slot = blockIdx.z / pairs;
-    W += slot * bs.mat;
-    T += slot * bs.mat;
-    const int a0 = 2 * q * sb, b0 = a0 + sb;
-    const int rows = min(sb, nb - b0);
-    const int ib = rows - 1 - (int)blockIdx.y, jb = HALF ? blockIdx.x >> 1 : blockIdx.x;      // long tiles (large ib) first
-    if (ib < 0) return;
-    if (HALF) {
-        __shared__ double ldh[HALF_LDS_DOUBLES];
-        const int h = blockIdx.x & 1;
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 64 + (lane & 15);
-        f64x4 acc[2][4];
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
-        const double* Ap = W + ((long)(b0 + ib) * PB + h * HALF_M) * ld + (long)b0 * PB;
-        const double* Bp = T + (long)b0 * PB * ld + (long)(a0 + jb) * PB;
-        // W[B,B] is lower triangular: the upper half of the rows ends 64 columns earlier (those products are exact zeros)
-        gemm_tile_64x128<false>(Ap, ld, Bp, ld, 0, ib * PB + (h + 1) * HALF_M, acc, ldh);
-        double* C = W + ((long)(b0 + ib) * PB + h * HALF_M) * ld + (long)(a0 + jb) * PB;
-#pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
-        return;
-    }
-    __shared__ double lds[GEMM_LDS_DOUBLES];
-    f64x4 acc[4][4];
-    acc_zero(acc);
-    const double* Ap = W + (long)(b0 + ib) * PB * ld + (long)b0 * PB;
-    const double* Bp = T + (long)b0 * PB * ld + (long)(a0 + jb) * PB;
-    gemm_tile_128<true, false, 0>(Ap, ld, Bp, ld, 0, (ib + 1) * PB, acc, lds);
-    double* C = W + (long)(b0 + ib) * PB * ld + (long)(a0 + jb) * PB;
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)acc_row(ta, r) * ld + acc_col(tb)] = -acc[ta][tb][r];
-}
-
-// Both steps on 64 x 64 quarter tiles (gemm_tile_64x64, k-major second operand): blockIdx.x = 4 * (x index) + 2 * (row half)
-// + (column half).  A level of the doubling is as long as its longest tile (the products shrink with the distance from the
-// diagonal), and four small workgroups per CU even that out better than two halves; same sums in the same order.
-__global__ __launch_bounds__(GEMM_THREADS, 4) void k_inv_step1_quarter(const double* __restrict__ L, const double* __restrict__ W,
-                                                                       double* __restrict__ T, long ld, int sb, int nb, BatchStride bs) {
-    const int pairs = (nb + 2 * sb - 1) / (2 * sb);
-    const int q = blockIdx.z % pairs, slot = blockIdx.z / pairs;
-    L += slot * bs.mat;
-    W += slot * bs.mat;
-    T += slot * bs.mat;
-    const int a0 = 2 * q * sb, b0 = a0 + sb;
-    const int rows = min(sb, nb - b0);
-    const int ib = blockIdx.x >> 2, jb = blockIdx.y;
-    if (ib >= rows) return;
-    const int hr = (blockIdx.x >> 1) & 1, hc = blockIdx.x & 1;
-    __shared__ double ldq[QUARTER_LDS_DOUBLES];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 32 + (lane & 15);
-    f64x4 acc[2][2];
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const double* Ap = L + ((long)(b0 + ib) * PB + hr * QUARTER_M) * ld + (long)a0 * PB;
-    const double* Bp = W + (long)a0 * PB * ld + (long)(a0 + jb) * PB + hc * QUARTER_M;
-    gemm_tile_64x64<false>(Ap, ld, Bp, ld, jb * PB, sb * PB, acc, ldq);
-    double* C = T + ((long)(b0 + ib) * PB + hr * QUARTER_M) * ld + (long)(a0 + jb) * PB + hc * QUARTER_M;
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = acc[ta][tb][r];
-}
-
-__global__ __launch_bounds__(GEMM_THREADS, 4) void k_inv_step2_quarter(double* __restrict__ W, const double* __restrict__ T, long ld,
-                                                                       int sb, int nb, BatchStride bs) {
-    const int pairs = (nb + 2 * sb - 1) / (2 * sb);
-    const int q = blockIdx.z % pairs, slot = blockIdx.z / pairs;
-    W += slot * bs.mat;
-    T += slot * bs.mat;
-    const int a0 = 2 * q * sb, b0 = a0 + sb;
-    const int rows = min(sb, nb - b0);
-    const int ib = rows - 1 - (int)blockIdx.y, jb = blockIdx.x >> 2;      // long tiles (large ib) first
-    if (ib < 0) return;
-    const int hr = (blockIdx.x >> 1) & 1, hc = blockIdx.x & 1;
-    __shared__ double ldq[QUARTER_LDS_DOUBLES];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row0 = (w >> 1) * 32 + (lane >> 4), col0 = (w & 1) * 32 + (lane & 15);
-    f64x4 acc[2][2];
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const double* Ap = W + ((long)(b0 + ib) * PB + hr * QUARTER_M) * ld + (long)b0 * PB;
-    const double* Bp = T + (long)b0 * PB * ld + (long)(a0 + jb) * PB + hc * QUARTER_M;
-    // W[B,B] is lower triangular: the upper half of the rows ends 64 columns earlier (those products are exact zeros)
-    gemm_tile_64x64<false>(Ap, ld, Bp, ld, 0, ib * PB + (hr + 1) * QUARTER_M, acc, ldq);
-    double* C = W + ((long)(b0 + ib) * PB + hr * QUARTER_M) * ld + (long)(a0 + jb) * PB + hc * QUARTER_M;
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)(row0 + ta * 16 + 4 * r) * ld + col0 + tb * 16] = -acc[ta][tb][r];
-}
-
-// Sums of N (a power of two, <= 32) per-lane values over the 64 lanes of a wave: on return every lane holds the total of
-// value lane / (64 / N).  Each exchange halves the number of values a lane carries (the half it gives up travels to the
-// partner lane): N - 1 exchanges plus a butterfly on the one value left, instead of N butterflies of six exchanges, and
-// none of them waits for another value's turn.  The pairing tree (partners at distance 32, 16, 8, 4, 2, 1) and
-// therefore every rounding is that of   for (o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o)   applied to each value.
-template <int N, int H>
-__device__ __forceinline__ void wave_sum_level(double (&s)[N], int lane) {
-    // H values stay, partner distance 64 H / N; compile-time recursion keeps every index of s a constant (a loop over
-    // the levels is not unrolled by the compiler, and s then turns into chains of selects)
-    constexpr int dist = 64 * H / N;
-    const bool up = (lane & dist) != 0;
-    double give[H];
-#pragma unroll
-    for (int u = 0; u < H; ++u) {
-        give[u] = up ? s[u] : s[u + H];
-        s[u] = up ? s[u + H] : s[u];
-    }
-#pragma unroll
-    for (int u = 0; u < H; ++u) give[u] = __shfl_xor(give[u], dist);     // all of a level's exchanges are in flight together
-#pragma unroll
-    for (int u = 0; u < H; ++u) s[u] += give[u];
-    if constexpr (H > 1) wave_sum_level<N, H / 2>(s, lane);
-}
-template <int N>
-__device__ __forceinline__ double wave_sum(double (&s)[N]) {
-    static_assert(N >= 2 && N <= 32 && (N & (N - 1)) == 0, "a power of two between 2 and 32");
-    const int lane = threadIdx.x & 63;
-    wave_sum_level<N, N / 2>(s, lane);
-    double r = s[0];
-#pragma unroll
-    for (int dist = 32 / N; dist >= 1; dist >>= 1) r += __shfl_xor(r, dist);
-    return r;
-}
-
-// ---------------------------------------------------------------------------------------
-// Triangular solves for one right-hand side, one launch per 128-block step.
-// Forward step p: z_p = inv(L_pp) w_p ; w_ib -= L[ib,p] z_p for ib > p.   grid = nb - p.
-constexpr int TRSV_FWD_THREADS = 512;              // eight waves, 16 rows each: both operands fit the registers without spills
-__global__ __launch_bounds__(TRSV_FWD_THREADS) void k_trsv_fwd_step(const double* __restrict__ L, long ld,
-                                                       const double* __restrict__ Dinv, double* __restrict__ w,
-                                                       double* __restrict__ z, int p, BatchStride bs,
-                                                       const double* __restrict__ gate) {
-    if (gate && gate[blockIdx.z * bs.par] == 0.0) return;      // a refinement solve the model does not need
-    __shared__ double yp[PB];
-    L += blockIdx.z * bs.mat;
-    Dinv += blockIdx.z * bs.dinv;
-    w += blockIdx.z * bs.vec;
-    z += blockIdx.z * bs.vec;
-    __shared__ double zp[PB];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // Both operands of the step (this wave's 16 rows of the inverted diagonal block and of the block of L below) are
-    // requested before anything is waited for: the step is a chain of memory round trips and little else, and this
-    // makes it one round trip instead of eight.  Row of value u: wv + 8 u.
-    const double* dinv = Dinv + (long)p * PB * PB;
-    const int ib = p + blockIdx.x;
-    const double* Lp = L + (long)ib * PB * ld + (long)p * PB;
-    double d0[16], d1[16], l0[16], l1[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int r = wv + 8 * u;
-        d0[u] = dinv[r * PB + lane];
-        d1[u] = dinv[r * PB + 64 + lane];
-    }
-    if (blockIdx.x != 0) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int r = wv + 8 * u;
-            l0[u] = Lp[(long)r * ld + lane];
-            l1[u] = Lp[(long)r * ld + 64 + lane];
-        }
-    }
-    if (tid < PB) yp[tid] = w[p * PB + tid];
-    __syncthreads();
-    const double y0 = yp[lane], y1 = yp[64 + lane];
-    double sv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) sv[u] = d0[u] * y0 + d1[u] * y1;
-    const double zsum = wave_sum<16>(sv);           // value lane >> 2
-    if ((lane & 3) == 0) zp[wv + 8 * (lane >> 2)] = zsum;
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid < PB) z[p * PB + tid] = zp[tid];
-        return;
-    }
-    const double z0 = zp[lane], z1 = zp[64 + lane];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) sv[u] = l0[u] * z0 + l1[u] * z1;
-    const double wsum = wave_sum<16>(sv);
-    if ((lane & 3) == 0) w[ib * PB + wv + 8 * (lane >> 2)] -= wsum;
-}
-
-// Backward step p (L^T x = z): x_p = inv(L_pp)^T z_p ; z_jb -= L[p,jb]^T x_p for jb < p.  grid = p + 1.
-__global__ __launch_bounds__(256) void k_trsv_bwd_step(const double* __restrict__ L, long ld,
-                                                       const double* __restrict__ Dinv, double* __restrict__ z,
-                                                       double* __restrict__ x, int p, BatchStride bs,
-                                                       const double* __restrict__ gate) {
-    if (gate && gate[blockIdx.z * bs.par] == 0.0) return;
-    __shared__ double zp[PB];
-    L += blockIdx.z * bs.mat;
-    Dinv += blockIdx.z * bs.dinv;
-    z += blockIdx.z * bs.vec;
-    x += blockIdx.z * bs.vec;
-    __shared__ double xp[PB];
-    __shared__ double red[256];
-    const int tid = threadIdx.x;
-    // as in the forward step: both operands are requested up front, one memory round trip per step
-    const double* dinv = Dinv + (long)p * PB * PB;
-    const int c = tid & 127, hh = tid >> 7;
-    const int jb = (int)blockIdx.x - 1;
-    const double* Lp = L + (long)p * PB * ld + (long)(jb < 0 ? 0 : jb) * PB;
-    double dv[64], lv[64];
-#pragma unroll
-    for (int u = 0; u < 64; ++u) dv[u] = dinv[(hh * 64 + u) * PB + c];
-    if (blockIdx.x != 0) {
-#pragma unroll
-        for (int u = 0; u < 64; ++u) lv[u] = Lp[(long)(hh * 64 + u) * ld + c];
-    }
-    if (tid < PB) zp[tid] = z[p * PB + tid];
-    __syncthreads();
-    {
-        double s = 0.0;
-#pragma unroll
-        for (int u = 0; u < 64; ++u) s += dv[u] * zp[hh * 64 + u];
-        red[tid] = s;
-    }
-    __syncthreads();
-    if (tid < PB) xp[tid] = red[tid] + red[tid + 128];
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid < PB) x[p * PB + tid] = xp[tid];
-        return;
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int u = 0; u < 64; ++u) s += lv[u] * xp[hh * 64 + u];
-    red[tid] = s;
-    __syncthreads();
-    if (tid < PB) z[jb * PB + tid] -= red[tid] + red[tid + 128];
-}
-
-// One step of iterative refinement of alpha1 = (K0 + eps I)^-1 y against the covariance matrix itself (rebuilt entry by
-// entry, the factor is not used for the residual): r = y - (K0 + eps I) alpha1, delta = L^-T L^-1 r, alpha1 += delta.
-// It removes what the blocked substitution (explicitly inverted 128x128 diagonal blocks) and the factor's backward error
-// add on top of a LAPACK-style solve when K0 + eps I is badly conditioned (sigmaY = 0: eps = 1e-15 n): theta1 = y.alpha1/n
-// is then off by ~cond * 1e-17 (1e-6 at cond 4e11), and with it the variance.  Gated on the device: k_refine_flag sets
-// params[P_REFINE] from (max diag L / min diag L)^2, and every kernel of the step returns at once when it is 0.
-constexpr double REFINE_COND = 1e7;
-__global__ __launch_bounds__(256) void k_refine_flag(const double* __restrict__ L, long ld, int n, double* __restrict__ params,
-                                                     BatchStride bs) {
-    __shared__ double lo[256], hi[256];
-    L += blockIdx.z * bs.mat;
-    params += blockIdx.z * bs.par;
-    const int tid = threadIdx.x;
-    double a = INFINITY, b = -INFINITY;
-    for (int i = tid; i < n; i += 256) {
-        const double v = L[(long)i * ld + i];
-        a = fmin(a, v);
-        b = fmax(b, v);
-    }
-    lo[tid] = a;
-    hi[tid] = b;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            lo[tid] = fmin(lo[tid], lo[tid + o]);
-            hi[tid] = fmax(hi[tid], hi[tid + o]);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double c = (hi[0] / lo[0]) * (hi[0] / lo[0]);
-        params[P_COND] = c;
-        params[P_REFINE] = (c > REFINE_COND) ? 1.0 : 0.0;      // NaN compares false: a failed factorisation is not refined
-    }
-}
-
-// r_i = y_i - sum_j k(x_i, x_j) a_j - eps a_i for REF_ROWS rows per workgroup; the row's products are summed over
-// j = tid, tid + 256, ... and then over the 256 threads in a fixed tree (deterministic).
-constexpr int REF_ROWS = 8;
-__global__ __launch_bounds__(256) void k_refine_residual(const double* __restrict__ Xts, int n, int n_pad, int d,
-                                                         const double* __restrict__ y, const double* __restrict__ a,
-                                                         double eps_val, const double* __restrict__ eps_ptr, int kernel,
-                                                         const double* __restrict__ params, double* __restrict__ r, BatchStride bs) {
-    if (params[blockIdx.z * bs.par + P_REFINE] == 0.0) return;
-    Xts += blockIdx.z * bs.xts;
-    y += blockIdx.z * bs.vec;
-    a += blockIdx.z * bs.vec;
-    r += blockIdx.z * bs.vec;
-    const double eps = eps_ptr ? eps_ptr[blockIdx.z * bs.slot] : eps_val;
-    __shared__ double red[REF_ROWS][256];
-    const int tid = threadIdx.x;
-    const int i0 = blockIdx.x * REF_ROWS;
-    double acc[REF_ROWS];
-#pragma unroll
-    for (int q = 0; q < REF_ROWS; ++q) acc[q] = 0.0;
-    for (int j = tid; j < n; j += 256) {
-        const double aj = a[j];
-        double D[REF_ROWS];
-#pragma unroll
-        for (int q = 0; q < REF_ROWS; ++q) D[q] = 0.0;
-        for (int t = 0; t < d; ++t) {
-            const double xj = Xts[(long)t * n_pad + j];
-            const double* xi = Xts + (long)t * n_pad + i0;
-#pragma unroll
-            for (int q = 0; q < REF_ROWS; ++q) {
-                const double df = xi[q] - xj;
-                D[q] += df * df;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < REF_ROWS; ++q) {
-            const int i = i0 + q;
-            const double kij = (i == j) ? 1.0 + eps : kern_eval(D[q], kernel);
-            acc[q] = fma(kij, aj, acc[q]);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < REF_ROWS; ++q) red[q][tid] = acc[q];
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-#pragma unroll
-            for (int q = 0; q < REF_ROWS; ++q) red[q][tid] += red[q][tid + o];
-        }
-        __syncthreads();
-    }
-    if (tid < REF_ROWS) {
-        const int i = i0 + tid;
-        r[i] = (i < n) ? y[i] - red[tid][0] : 0.0;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_refine_add(double* __restrict__ a, const double* __restrict__ delta, int n_pad,
-                                                    const double* __restrict__ params, BatchStride bs) {
-    if (params[blockIdx.z * bs.par + P_REFINE] == 0.0) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_pad) a[blockIdx.z * bs.vec + i] += delta[blockIdx.z * bs.vec + i];
-}
-
-// theta1 = y.alpha1/n, sum log diag L, -logL, scale factors and the alpha used for the mean.
-// One workgroup (deterministic order).
-__global__ __launch_bounds__(256) void k_fit_scalars(const double* __restrict__ L, long ld, const double* __restrict__ y,
-                                                     const double* __restrict__ alpha1, double* __restrict__ alpha_out,
-                                                     int n, int n_pad, int variant, double* __restrict__ params,
-                                                     BatchStride bs) {
-    __shared__ double r1[256];
-    L += blockIdx.z * bs.mat;
-    y += blockIdx.z * bs.vec;
-    alpha1 += blockIdx.z * bs.vec;
-    alpha_out += blockIdx.z * bs.vec;
-    params += blockIdx.z * bs.par;
-    __shared__ double r2[256];
-    __shared__ double r3[256];
-    const int tid = threadIdx.x;
-    double ya = 0.0, sl = 0.0, ym = -INFINITY;
-    for (int i = tid; i < n; i += 256) {
-        ya += y[i] * alpha1[i];
-        sl += log(L[(long)i * ld + i]);
-        ym = fmax(ym, y[i]);
-    }
-    r1[tid] = ya;
-    r2[tid] = sl;
-    r3[tid] = ym;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            r1[tid] += r1[tid + o];
-            r2[tid] += r2[tid + o];
-            r3[tid] = fmax(r3[tid], r3[tid + o]);
-        }
-        __syncthreads();
-    }
-    const double theta1 = r1[0] / n;
-    if (tid == 0) {
-        params[P_YA] = r1[0];
-        params[P_SUMLOG] = r2[0];
-        params[P_THETA1] = theta1;
-        params[P_YMAX] = r3[0];
-        params[P_NLL] = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(theta1) + r2[0];
-        params[P_CLAMP] = 1.0;
-        params[P_NBETA] = 0.0;
-        params[P_DEG] = 0.0;
-        if (variant != 1) {      // two-factor forms (v4 and the MATLAB form): theta1-scaled covariances, eps unscaled
-            params[P_CB] = theta1;
-            params[P_C0] = theta1;
-            params[P_C1] = 1.0;
-        } else {
-            params[P_CB] = 1.0;
-            params[P_C0] = theta1;
-            params[P_C1] = theta1;
-        }
-    }
-    for (int i = tid; i < n_pad; i += 256) alpha_out[i] = (i < n) ? (variant != 1 ? alpha1[i] / theta1 : alpha1[i]) : 0.0;
-}
-
-// -logL as the MATLAB two-factor form reports it (GP/BayesOpt_v3.m:362): n/2 (log 2 pi + 1) + n/2 log(y.alpha2 / n) +
-// sum log diag L2, with alpha2 and L2 of the SECOND factorisation (theta1 K0 + eps).  One workgroup, fixed order.
-__global__ __launch_bounds__(256) void k_nll_second_factor(const double* __restrict__ L2, long ld, const double* __restrict__ y,
-                                                           const double* __restrict__ alpha2, int n, double* __restrict__ params) {
-    __shared__ double r1[256];
-    __shared__ double r2[256];
-    const int tid = threadIdx.x;
-    double ya = 0.0, sl = 0.0;
-    for (int i = tid; i < n; i += 256) {
-        ya += y[i] * alpha2[i];
-        sl += log(L2[(long)i * ld + i]);
-    }
-    r1[tid] = ya;
-    r2[tid] = sl;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            r1[tid] += r1[tid + o];
-            r2[tid] += r2[tid + o];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) params[P_NLL] = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(r1[0] / n) + r2[0];
-}
-
-// ---------------------------------------------------------------------------------------
-// K(X*,X) chunk: Bmat[k][j] = cb * k(D(x_k, xs_j)) for k < n (0 for the pad), j over the chunk
-// (j contiguous), plus partial means  mupart[kc][j] = sum_{k in chunk kc} Bmat[k][j] * alpha[k].
-// One thread per candidate; a workgroup covers KS_ROWS training rows, whose scaled coordinates and alpha are staged in
-// LDS once (row-major, read back as broadcasts).  Measured against wave-uniform scalar loads of the same values
-// (scripts/ks_gemm_ab.hip): 0.218 vs 0.243 ms per 4096 x 32768 panel at d = 4, 0.371 vs 0.547 ms per 32768 x 4096 panel at
-// d = 8 with the Matern kernel -- all of what the GEMM form of the distance gains (0.225 / 0.357 ms), without its
-// cancellation error (18-28 ulp against 1-2 ulp).  D = 0: any d up to MAX_D, coordinates straight from global memory.
-constexpr int KS_ROWS = 512;
-template <int D>
-__global__ __launch_bounds__(256) void k_ks_build(const double* __restrict__ Xs, long m, long j0, int d_rt,
-                                                  const double* __restrict__ Xts, int n, int n_pad,
-                                                  const double* __restrict__ alpha, const double* __restrict__ params,
-                                                  double* __restrict__ Bmat, long ldb, double* __restrict__ mupart, int kc,
-                                                  int kernel) {
-    const int d = (D > 0) ? D : d_rt;
-    const long jl = (long)blockIdx.x * 256 + threadIdx.x;   // column in the chunk
-    long j = j0 + jl;
-    if (j >= m) j = m - 1;                                   // padded columns: recompute the last candidate
-    const double cb = params[P_CB];
-    const int k_lo = blockIdx.y * kc;
-    const int k_hi = min(k_lo + kc, n_pad);
-    double xs[(D > 0) ? D : MAX_D];
-#pragma unroll
-    for (int t = 0; t < ((D > 0) ? D : MAX_D); ++t)
-        if (t < d) xs[t] = Xs[j * d + t] * params[P_INVTHETA + t];
-    double mu = 0.0;
-    if (D > 0) {
-        __shared__ double xr[KS_ROWS * ((D > 0) ? D : 1)];
-        __shared__ double al[KS_ROWS];
-        const int rows = k_hi - k_lo;                        // kc == KS_ROWS for this form (the launch guarantees it)
-        for (int idx = threadIdx.x; idx < rows * D; idx += 256) {
-            const int t = idx / rows, k = idx - t * rows;    // coalesced over k for a fixed dimension
-            xr[k * D + t] = Xts[(long)t * n_pad + k_lo + k];
-        }
-        for (int k = threadIdx.x; k < rows; k += 256) al[k] = alpha[k_lo + k];
-        __syncthreads();
-        const int live = min(rows, max(n - k_lo, 0));        // rows below n hold data, the rest is the pad
-        double* Bp = Bmat + (long)k_lo * ldb + jl;
-        auto entry = [&](int k) {
-            double Dq = 0.0;
-#pragma unroll
-            for (int t = 0; t < D; ++t) {
-                const double df = xs[t] - xr[k * D + t];
-                Dq += df * df;
-            }
-            const double v = cb * kern_eval(Dq, kernel);
-            mu += v * al[k];
-            Bp[(long)k * ldb] = v;
-        };
-        if (live == KS_ROWS) {                               // the common case: a constant trip count the compiler can pipeline
-#pragma unroll 4
-            for (int k = 0; k < KS_ROWS; ++k) entry(k);
-        } else {
-            for (int k = 0; k < live; ++k) entry(k);
-            for (int k = live; k < rows; ++k) Bp[(long)k * ldb] = 0.0;
-        }
-    } else {
-        for (int k = k_lo; k < k_hi; ++k) {
-            double v = 0.0;
-            if (k < n) {
-                double Dq = 0.0;
-                for (int t = 0; t < d; ++t) {
-                    const double df = xs[t] - Xts[(long)t * n_pad + k];
-                    Dq += df * df;
-                }
-                v = cb * kern_eval(Dq, kernel);
-                mu += v * alpha[k];
-            }
-            Bmat[(long)k * ldb + jl] = v;
-        }
-    }
-    mupart[(long)blockIdx.y * ldb + jl] = mu;
-}
-
-// V = W * Bmat (W lower triangular), fused epilogue: per-column sum of squares of the
-// 128 rows of the tile -> partial[ib][j].
-// STORE_V: also keep V rows < v_rows of the tile in the resident buffer Vres[row][j0 + col]
-// (row pitch ldv = number of candidates) for the incremental append path.
-//
-// Tile order: groups of cg column blocks; inside a group row blocks heaviest first (longest k range), the group's column
-// blocks of a row block next to each other, so the resident tiles share few W row panels (served from L2) and the tail
-// of a launch consists of one-k-block tiles.  Groups of 128 column blocks against one group of 256 (the whole chunk):
-// +2.4 % on two machines, -0.2 % on a third that ran both at the higher rate; narrower groups lose (48: -3 %, 8: -9 %);
-// alternating heavy and light row blocks loses 1-2 %.  An XCD-aware 8x8 super-tile order that also shares the Ks panels
-// measured 9 % slower (tiles marching through k in lockstep expose the miss latency); bands of 2 / 4 / 8 row blocks per
-// column block, dispatched together: -3 / -10 / -20 % at 32 row blocks, -0.3 / -1.2 / -2.8 % at 256.  Persistent workgroups that chain
-// their tiles (no prologue) and draw them from a counter: +0.7 % with one counter but 20 GB instead of 12 GB fetched per
-// launch (the row blocks of a column block no longer meet in one L2), -0.5 % with a counter per XCD; with a static
-// assignment -4 % (workgroups do not progress at equal rates).  The hardware dispatcher's order stays.
-// MODE: the tile engine's scheduling mode; 2 (priority raise + fragment prefetch) is never worse than 0 or 1 here: equal to
-// the better of them at 32 row blocks, whichever that is on the machine at hand, and +0.9 % at 256.
-template <bool STORE_V, int MODE>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trmm_sumsq(const double* __restrict__ W, long ld,
-                                                             const double* __restrict__ Bmat, long ldb,
-                                                             double* __restrict__ partial, int nb, int nj,
-                                                             double* __restrict__ Vres, long ldv, long j0, long m, int v_rows,
-                                                             int cg) {
-    const int per = nb * cg;
-    const int grp = blockIdx.x / per, r = blockIdx.x % per;
-    const int cw = min(cg, nj - grp * cg);              // the last group may be narrower
-    const int ib = nb - 1 - r / cw;
-    const int jb = grp * cg + r % cw;
-    __shared__ double lds[GEMM_LDS_DOUBLES];
-    f64x4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_128<true, false, MODE>(W + (long)ib * PB * ld, ld, Bmat + (long)jb * TN, ldb, 0, (ib + 1) * PB, acc, lds, ib * PB);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    if (STORE_V) {
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = ib * PB + acc_row(ta, r);
-                    const long col = j0 + (long)jb * TN + acc_col(tb);
-                    if (row < v_rows && col < m) Vres[(long)row * ldv + col] = acc[ta][tb][r];
-                }
-    }
-    double cs[4];
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-        double s = 0.0;
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s += acc[ta][tb][r] * acc[ta][tb][r];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        cs[tb] = s;
-    }
-    double* red = lds;   // the tile engine ended on a barrier: LDS is free
-    if ((lane >> 4) == 0) {
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) red[wr * 128 + wc * 64 + tb * 16 + lane] = cs[tb];
-    }
-    __syncthreads();
-    if (tid < 128) partial[(long)ib * ldb + (long)jb * TN + tid] = red[tid] + red[128 + tid];
-}
-
-// Trend basis of the kriging flavour (polymat, Gaussian_Process_Regression.ipynb:113-140): columns for
-// C = 1..3 inputs and degree 0..3, in the reference's column order.  Returns f(x) . beta.
-__device__ __forceinline__ double trend_eval(const double* __restrict__ x, int C, int deg, const double* __restrict__ beta) {
-    double f = beta[0];
-    if (deg == 0) return f;
-    if (C == 1) {
-        f += beta[1] * x[0];
-        if (deg >= 2) f += beta[2] * x[0] * x[0];
-    } else if (C == 2) {
-        f += beta[1] * x[0] + beta[2] * x[1];
-        if (deg >= 2) f += beta[3] * x[0] * x[0] + beta[4] * x[1] * x[1];
-        if (deg >= 3) f += beta[5] * x[0] * x[1];
-    } else {
-        f += beta[1] * x[0] + beta[2] * x[1] + beta[3] * x[2];
-        if (deg >= 2) f += beta[4] * x[0] * x[0] + beta[5] * x[1] * x[1] + beta[6] * x[2] * x[2];
-        if (deg >= 3) f += beta[7] * x[0] * x[1] + beta[8] * x[0] * x[2] + beta[9] * x[1] * x[2];
-    }
-    return f;
-}
-
-// var = c0 - c1 * sum_ib partial[ib][j] (clamped: < 1e-60 -> 0 unless the model says otherwise),
-// mu = sum_kc mupart[kc][j] (+ trend for the kriging flavour).
-__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partial, const double* __restrict__ mupart,
-                                                  long ldb, int nb, int nkc, const double* __restrict__ params,
-                                                  double* __restrict__ mu, double* __restrict__ var, long j0, long m,
-                                                  double* __restrict__ sres, const double* __restrict__ Xs, int d) {
-    const long jl = (long)blockIdx.x * 256 + threadIdx.x;
-    const long j = j0 + jl;
-    if (jl >= ldb || j >= m) return;
-    double s = 0.0;
-    for (int ib = 0; ib < nb; ++ib) s += partial[(long)ib * ldb + jl];
-    double mm = 0.0;
-    for (int c = 0; c < nkc; ++c) mm += mupart[(long)c * ldb + jl];
-    double v = params[P_C0] - params[P_C1] * s;
-    if (params[P_CLAMP] != 0.0 && v < 1e-60) v = 0.0;
-    const int nbeta = (int)params[P_NBETA];
-    if (nbeta > 0) {
-        double x[3] = {0.0, 0.0, 0.0};
-        for (int t = 0; t < d && t < 3; ++t) x[t] = Xs[j * d + t];
-        mm += trend_eval(x, d, (int)params[P_DEG], params + P_BETA);
-    }
-    mu[j] = mm;
-    var[j] = v;
-    if (sres) sres[j] = s;
-}
-
-// ---------------------------------------------------------------------------------------
-// Reductions: max and (value, first index) argmax, two stages, deterministic.
-// Both follow NumPy on NaN: a maximum that meets a NaN is NaN (np.max, BayesOpt_v4.ipynb:193), and the argmax returns the
-// first NaN if there is one (np.argmax, :647), so a poisoned posterior surfaces instead of being masked.
-__device__ __forceinline__ double max_nan(double a, double b) { return (a > b || a != a) ? a : b; }
-// out2 (optional, single-workgroup launches): a second destination for the result (the incumbent slot of the acquisition)
-__global__ __launch_bounds__(256) void k_max_stage(const double* __restrict__ a, long m, double* __restrict__ out,
-                                                   double* __restrict__ out2 = nullptr) {
-    __shared__ double r[256];
-    const int tid = threadIdx.x;
-    double v = -INFINITY;
-    for (long i = (long)blockIdx.x * 256 + tid; i < m; i += (long)gridDim.x * 256) v = max_nan(v, a[i]);
-    r[tid] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) r[tid] = max_nan(r[tid], r[tid + o]);
-        __syncthreads();
-    }
-    if (tid == 0) {
-        out[blockIdx.x] = r[0];
-        if (out2) out2[blockIdx.x] = r[0];
-    }
-}
-
-// The new scaled point of a loop step, passed to the step's first kernel by value.
-struct PointArg {
-    double x[MAX_D];
-};
-
-// End of a loop step: everything the host reads back, gathered into one block (pinned host memory mapped into the
-// device's address space: the kernel's stores are the transfer).  res: [0..7] params head, [8] info, [9] max(mu),
-// [10] best acquisition value, [11] its index (bit pattern of an int64).
-constexpr int STEP_RES_DOUBLES = 16;
-__global__ void k_step_end(const double* __restrict__ params, const int* __restrict__ info, const double* __restrict__ mu_max,
-                           const double* __restrict__ best_v, const long* __restrict__ best_i, double* __restrict__ res) {
-    const int t = threadIdx.x;
-    if (t < 8) res[t] = params[t];
-    if (t == 8) res[8] = (double)*info;
-    if (t == 9) res[9] = *mu_max;
-    if (t == 10) res[10] = *best_v;
-    if (t == 11) reinterpret_cast<long*>(res)[11] = *best_i;
-}
-
-// (v, i) goes ahead of (bv, bi): a NaN ranks above every number, equal ranks go to the lower index.  A total order, so
-// the winner does not depend on the shape of the reduction.
-__device__ __forceinline__ bool better(double v, long i, double bv, long bi) {
-    const bool vn = v != v, bn = bv != bv;
-    if (vn || bn) return vn && (!bn || i < bi);
-    return (v > bv) || (v == bv && i < bi);
-}
-
-// The last stage of the argmax (over the per-workgroup results of k_acquire_argmax) and the end-of-step block in one
-// single-workgroup launch: res[10] / res[11] receive the winner, the rest as k_step_end.  Which of several equal values wins
-// is decided by the index alone, so the result does not depend on the shape of the reduction.
-__global__ __launch_bounds__(1024) void k_argmax_step_end(const double* __restrict__ pv, const long* __restrict__ pi, long m,
-                                                          const double* __restrict__ params, const int* __restrict__ info,
-                                                          const double* __restrict__ mu_max, double* __restrict__ res) {
-    __shared__ double rv[1024];
-    __shared__ long ri[1024];
-    const int tid = threadIdx.x;
-    double bv = -INFINITY;
-    long bi = INT64_MAX;
-    for (long i0 = tid; i0 < m; i0 += 4096) {
-        double v[4];
-        long g[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long i = i0 + u * 1024;
-            v[u] = (i < m) ? pv[i] : -INFINITY;
-            g[u] = (i < m) ? pi[i] : INT64_MAX;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (better(v[u], g[u], bv, bi)) {
-                bv = v[u];
-                bi = g[u];
-            }
-    }
-    rv[tid] = bv;
-    ri[tid] = bi;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o && better(rv[tid + o], ri[tid + o], rv[tid], ri[tid])) {
-            rv[tid] = rv[tid + o];
-            ri[tid] = ri[tid + o];
-        }
-        __syncthreads();
-    }
-    if (tid < 8) res[tid] = params[tid];
-    if (tid == 8) res[8] = (double)*info;
-    if (tid == 9) res[9] = *mu_max;
-    if (tid == 10) res[10] = rv[0];
-    if (tid == 11) reinterpret_cast<long*>(res)[11] = ri[0];
-}
-
-__global__ __launch_bounds__(256) void k_argmax_stage(const double* __restrict__ a, const long* __restrict__ idx_in, long m,
-                                                      double* __restrict__ out_v, long* __restrict__ out_i) {
-    __shared__ double rv[256];
-    __shared__ long ri[256];
-    const int tid = threadIdx.x;
-    double bv = -INFINITY;
-    long bi = INT64_MAX;
-    for (long i = (long)blockIdx.x * 256 + tid; i < m; i += (long)gridDim.x * 256) {
-        const double v = a[i];
-        const long gi = idx_in ? idx_in[i] : i;
-        if (better(v, gi, bv, bi)) {
-            bv = v;
-            bi = gi;
-        }
-    }
-    rv[tid] = bv;
-    ri[tid] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o && better(rv[tid + o], ri[tid + o], rv[tid], ri[tid])) {
-            rv[tid] = rv[tid + o];
-            ri[tid] = ri[tid + o];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        out_v[blockIdx.x] = rv[0];
-        out_i[blockIdx.x] = ri[0];
-    }
-}
-
-// Lowest index i with a[i] >= thr (INT64_MAX if none); stage 1 over the array, stage 2 over the per-workgroup results.
-__global__ __launch_bounds__(256) void k_first_ge_stage(const double* __restrict__ a, const long* __restrict__ idx_in, long m,
-                                                        double thr, long* __restrict__ out_i) {
-    __shared__ long ri[256];
-    const int tid = threadIdx.x;
-    long bi = INT64_MAX;
-    for (long i = (long)blockIdx.x * 256 + tid; i < m; i += (long)gridDim.x * 256) {
-        if (idx_in) {
-            if (idx_in[i] < bi) bi = idx_in[i];
-        } else if (a[i] >= thr && i < bi) {
-            bi = i;
-        }
-    }
-    ri[tid] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o && ri[tid + o] < ri[tid]) ri[tid] = ri[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) out_i[blockIdx.x] = ri[0];
-}
-
-// erfc(z) for z >= 0 as  t exp(-z^2) G(2t - 1),  t = 2 / (2 + z):  G(u) = exp(z^2) erfc(z) / t is smooth on [-1, 1]
-// (1 / (2 sqrt(pi)) at u = -1, i.e. z = inf; 1 at u = 1, i.e. z = 0) and its Chebyshev series converges like 0.2^k.  The 28
-// coefficients below were obtained by projecting G onto T_0 .. T_95 in 60-digit arithmetic; truncated here the series is
-// within 9e-18 (relative) of G over the whole range.  One formula for every z: no range branches for a wave to diverge
-// on, and the exponential is the one the normal density needs as well.
-__device__ __forceinline__ double erfcx_over_t(double u) {
-    constexpr double c[28] = {
-        0.57703373861646968862,     0.35543692127049848731,     0.06509515882878652455,     0.0036711423958366391659,
-        -0.0011128447433526324969,  -0.00016075829915378079758, 0.000032780315741731370605, 5.4424416455050160333e-6,
-        -1.5154665553171481622e-6,  -1.4297608181169864917e-7,  8.234608827419493433e-8,    -1.2962846852306562536e-9,
-        -4.1547216310151983042e-9,  6.3470582783628111814e-10,  1.4320822712256223707e-10,  -6.1603901052045855418e-11,
-        2.0612138554721696306e-12,  3.571493148847704445e-12,   -8.5864228432517964757e-13, -6.145600213790630554e-14,
-        7.4187257485966170573e-14,  -1.2895042755032325615e-14, -2.3587263857106323568e-15, 1.5729349381685911397e-15,
-        -2.2782966239546465174e-16, -6.3123304507564298101e-17, 3.5916763531814922992e-17,  -5.0498091498477292793e-18};
-    const double u2 = 2.0 * u;
-    double b1 = 0.0, b2 = 0.0;
-#pragma unroll
-    for (int k = 27; k >= 1; --k) {          // Clenshaw
-        const double b0 = fma(u2, b1, c[k] - b2);
-        b2 = b1;
-        b1 = b0;
-    }
-    return fma(u, b1, c[0] - b2);
-}
-
-// One candidate's acquisition value: EI (BayesOpt_v4.ipynb:188-197: imp Phi(Z) + sigma phi(Z), ei[sigma == 0] = 0), UCB
-// (GP/BayesOpt_v1.m:248-251) or PI (Gaussian_Process_Regression.ipynb:265-268).  Phi(Z) = erfc(-Z / sqrt 2) / 2 for Z < 0 and
-// 1 - erfc(Z / sqrt 2) / 2 otherwise, phi(Z) = exp(-Z^2 / 2) / sqrt(2 pi): one exponential serves both.  Every kernel that
-// evaluates an acquisition goes through this function, so their results agree bit for bit.  sigma = 0: Z = +-inf gives
-// Phi = 0 or 1 (t = 0, exp(-inf) = 0); 0 / 0 gives NaN under PI, as norm.cdf(nan) does.
-__device__ __forceinline__ double acq_value(double mj, double vj, double inc, int acq, double kappa) {
-    const double sigma = sqrt(vj);
-    if (acq == 1) return mj + kappa * sigma;
-    const double imp = (acq == 0) ? mj - inc - kappa : mj - inc;
-    const double Z = imp / sigma;
-    const double z = fabs(Z) * 0.70710678118654752440;
-    const double t = 2.0 / (2.0 + z);
-    const double ZZ = Z * Z;
-    const double E = exp(-ZZ / 2.0);             // the density's exponential, formed as the reference forms it
-    // for the distribution function the rounding of Z * Z (worth Z^2 ulp in the far tail) is put back: exp(-(ZZ + e) / 2) = E (1 - e / 2)
-    const double Ec = (ZZ < INFINITY) ? fma(E, -0.5 * fma(Z, Z, -ZZ), E) : E;
-    const double half_erfc = 0.5 * t * Ec * erfcx_over_t(2.0 * t - 1.0);
-    const double Phi = (Z < 0.0) ? half_erfc : 1.0 - half_erfc;
-    if (acq == 2) return Phi;
-    double r = imp * Phi + sigma * (E * 0.39894228040143267794);
-    if (sigma == 0.0) r = 0.0;
-    return r;
-}
-
-// Acquisition over the resident posterior.  inc_ptr: device scalar incumbent (EI/PI).
-__global__ __launch_bounds__(256) void k_acquire(const double* __restrict__ mu, const double* __restrict__ var, long m, int acq,
-                                                 double kappa, const double* __restrict__ inc_ptr,
-                                                 double* __restrict__ out) {
-    const long j = (long)blockIdx.x * 256 + threadIdx.x;
-    if (j >= m) return;
-    out[j] = acq_value(mu[j], var[j], *inc_ptr, acq, kappa);
-}
-
-// Acquisition and stage 1 of the first-occurrence argmax in one pass over (mu, var): a workgroup covers ACQ_SPAN
-// consecutive candidates, a thread ACQ_PER of them at stride 256 (coalesced), ascending, so "strictly greater" keeps the
-// lowest index; the workgroup's (value, index) goes to part_v / part_i.  STORE: also write the values to out.
-constexpr int ACQ_PER = 8;
-constexpr int ACQ_SPAN = 256 * ACQ_PER;
-// n_parts > 0: the incumbent is the maximum of inc_parts[0 .. n_parts) (n_parts <= 256: the second-stage results of the
-// max(mu) reduction), which every workgroup reduces for itself instead of waiting for a launch that does it once; workgroup 0
-// leaves it in inc_out[0] (incumbent) and inc_out[1] (max(mu)).  A maximum does not depend on the order it is taken in.
-// The maximum of up to 256 partial maxima, by every thread of a 256-thread workgroup (rv: 4 doubles of shared memory).
-__device__ __forceinline__ double block_max_of_parts(const double* __restrict__ parts, int n_parts, double* rv) {
-    const int tid = threadIdx.x;
-    double v = (tid < n_parts) ? parts[tid] : -INFINITY;
-    for (int o = 32; o > 0; o >>= 1) v = max_nan(v, __shfl_xor(v, o));
-    if ((tid & 63) == 0) rv[tid >> 6] = v;
-    __syncthreads();
-    const double r = max_nan(max_nan(rv[0], rv[1]), max_nan(rv[2], rv[3]));
-    __syncthreads();
-    return r;
-}
-
-template <bool STORE>
-__global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict__ mu, const double* __restrict__ var, long m, int acq,
-                                                        double kappa, const double* __restrict__ inc_ptr, double* __restrict__ out,
-                                                        double* __restrict__ part_v, long* __restrict__ part_i,
-                                                        const double* __restrict__ inc_parts = nullptr, int n_parts = 0,
-                                                        double* __restrict__ inc_out = nullptr,
-                                                        const double* __restrict__ c01 = nullptr) {
-    // c01 != nullptr: `var` holds sum v^2 per candidate and the variance is c01[0] - c01[1] * var[j] (< 1e-60 -> 0), as the
-    // lattice route of an append leaves it
-    __shared__ double rv[256];
-    __shared__ long ri[256];
-    const int tid = threadIdx.x;
-    const long base = (long)blockIdx.x * ACQ_SPAN;
-    double inc;
-    if (n_parts > 0) {
-        inc = block_max_of_parts(inc_parts, n_parts, rv);
-        if (blockIdx.x == 0 && tid == 0) {
-            inc_out[0] = inc;
-            inc_out[1] = inc;
-        }
-    } else {
-        inc = *inc_ptr;
-    }
-    double bv = -INFINITY;
-    long bi = INT64_MAX;
-#pragma unroll
-    for (int u = 0; u < ACQ_PER; ++u) {
-        const long j = base + u * 256 + tid;
-        if (j < m) {
-            double vj = var[j];
-            if (c01) {
-                vj = c01[0] - c01[1] * vj;
-                if (vj < 1e-60) vj = 0.0;
-            }
-            const double r = acq_value(mu[j], vj, inc, acq, kappa);
-            if (STORE) out[j] = r;
-            if (better(r, j, bv, bi)) {
-                bv = r;
-                bi = j;
-            }
-        }
-    }
-    rv[tid] = bv;
-    ri[tid] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o && better(rv[tid + o], ri[tid + o], rv[tid], ri[tid])) {
-            rv[tid] = rv[tid + o];
-            ri[tid] = ri[tid + o];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        part_v[blockIdx.x] = rv[0];
-        part_i[blockIdx.x] = ri[0];
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------
-// Batched likelihood sweep helpers.
-// Per setting: Xts[t][i] = Xraw[t][i] / theta[t], params[P_INVTHETA + t] = 1 / theta[t].
-__global__ __launch_bounds__(256) void k_setup_setting(const double* __restrict__ Xraw, const double* __restrict__ theta,
-                                                       int d, int n_pad, double* __restrict__ Xts, double* __restrict__ params,
-                                                       BatchStride bs) {
-    theta += blockIdx.z * bs.slot;
-    Xts += blockIdx.z * bs.xts;
-    params += blockIdx.z * bs.par;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int t = blockIdx.y;
-    const double it = 1.0 / theta[t];
-    if (i < n_pad) Xts[(long)t * n_pad + i] = Xraw[(long)t * n_pad + i] * it;
-    if (i == 0) params[P_INVTHETA + t] = it;
-}
-
-// Gradient of -logL w.r.t. theta:  g_t = -1/2 sum_{j,k} c_jk dK_t[j][k],
-//   c_jk = n a_j a_k / (y.a) - Kinv_jk,  Kinv = W^T W,  dK_t[j][k] = q_t F_jk / theta_t  (F = K0 for RBF, see kern_dfac),
-//   q_t = ((x_jt - x_kt)/theta_t)^2.
-// One workgroup = one lower tile (jb >= kb) of Kinv on the MFMA tile engine, reduced against dK_t
-// in the epilogue without ever storing Kinv.  gpart[(jb*nb + kb)*GRAD_D + t] = sum_tile c_jk q_t K0_jk
-// (x2 for off-diagonal tiles); the caller zero-fills gpart.
-constexpr int GRAD_D = 16;
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_lml_grad_tiles(const double* __restrict__ W, long ld,
-                                                                    const double* __restrict__ Xts, int n, int n_pad, int d,
-                                                                    const double* __restrict__ alpha1,
-                                                                    const double* __restrict__ params,
-                                                                    double* __restrict__ gpart, int nb, int kernel, BatchStride bs) {
-    W += blockIdx.z * bs.mat;
-    Xts += blockIdx.z * bs.xts;
-    alpha1 += blockIdx.z * bs.vec;
-    params += blockIdx.z * bs.par;
-    gpart += blockIdx.z * bs.gp;
-    int jb, kb;                    // 1-D grid over the lower tiles; jb ascending = longest contraction first
-    tri_decode(blockIdx.x, jb, kb);
-    __shared__ double lds[GEMM_LDS_DOUBLES];
-    f64x4 acc[4][4];
-    acc_zero(acc);
-    // A(j, r) = W[r][jb*128 + j], B(r, k) = W[r][kb*128 + k]; W[r][j] = 0 for r < j
-    gemm_tile_128<false, false>(W + (long)jb * PB, ld, W + (long)kb * PB, ld, jb * PB, n_pad, acc, lds);
-    // The epilogue keeps nothing but the 64 accumulators live (two workgroups per CU): the tile's scaled coordinates
-    // and alpha go through LDS (the tile engine ended on a barrier), c_jk K0_jk overwrites the accumulator, and the
-    // d sums are formed one dimension at a time.
-    const int tid = threadIdx.x;
-    double* xj = lds;                        // [GRAD_D][128]
-    double* xk = lds + GRAD_D * PB;          // [GRAD_D][128]
-    double* aj = lds + 2 * GRAD_D * PB;      // [128]
-    double* ak = aj + PB;                    // [128]
-    double* red = ak + PB;                   // [4][GRAD_D]
-    for (int idx = tid; idx < d * PB; idx += GEMM_THREADS) {
-        const int t = idx >> 7, i = idx & 127;
-        xj[idx] = Xts[(long)t * n_pad + jb * PB + i];
-        xk[idx] = Xts[(long)t * n_pad + kb * PB + i];
-    }
-    if (tid < PB) aj[tid] = alpha1[jb * PB + tid];
-    else ak[tid - PB] = alpha1[kb * PB + tid - PB];
-    __syncthreads();
-    const double scale_c = (double)n / params[P_YA];
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-        const int kc = acc_col(tb);
-        const int k = kb * PB + kc;
-#pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jr = acc_row(ta, r);
-                const int j = jb * PB + jr;
-                double Dq = 0.0;
-                for (int t = 0; t < d; ++t) {
-                    const double df = xj[t * PB + jr] - xk[t * PB + kc];
-                    Dq += df * df;
-                }
-                const double c = (scale_c * aj[jr] * ak[kc] - acc[ta][tb][r]) * kern_dfac(Dq, kernel);
-                acc[ta][tb][r] = (j < n && k < n && j != k) ? c : 0.0;
-            }
-    }
-    for (int t = 0; t < d; ++t) {
-        double g = 0.0;
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
-            const double xkt = xk[t * PB + acc_col(tb)];
-#pragma unroll
-            for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double df = xj[t * PB + acc_row(ta, r)] - xkt;
-                    g += acc[ta][tb][r] * (df * df);
-                }
-        }
-        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
-        if ((tid & 63) == 0) red[(tid >> 6) * GRAD_D + t] = g;
-    }
-    __syncthreads();
-    const double wgt = (jb == kb) ? 1.0 : 2.0;
-    if (tid < GRAD_D)
-        gpart[((long)jb * nb + kb) * GRAD_D + tid] =
-            (tid < d) ? wgt * (red[tid] + red[GRAD_D + tid] + red[2 * GRAD_D + tid] + red[3 * GRAD_D + tid]) : 0.0;
-}
-
-// Whole -logL (+ gradient) evaluation of ONE hyper-parameter setting in ONE workgroup, for n <= 128: covariance
-// tiles built in registers, factor and inverse by the diagonal-block kernel's MFMA routines, z = W y, alpha = W^T z, the
-// scalars, then Kinv = W^T W tile by tile out of LDS and the gradient sums.  grid = number of settings: a
-// multi-start fit on ~100 points is one launch instead of ten launches per setting.
-//   nll = n/2 (log 2pi + 1) + n/2 log(theta1) + sum log diag L,  theta1 = y.alpha / n       (mlefcn)
-//   g_t = -1/(2 theta_t) sum_{j != k} (n a_j a_k / (y.a) - Kinv_jk) q_t F_jk   (jacmlefun; F = K0 for RBF, kern_dfac)
-// LDS: W with pitch 129 (the packed copy of L lives in the same space while the inverse runs), scaled inputs, vectors.
-constexpr int SMALL_WP = PB + 1;
-constexpr int SMALL_WIDE_THREADS = 1024;       // workgroup of the one-workgroup routines for larger n (256 threads for small n)
-constexpr int SMALL_LDS_DOUBLES = PB * SMALL_WP + GRAD_D * PB + 6 * PB + 16 * GRAD_D + 8;
-// The evaluation itself, for one setting: th (d length scales, any address space), sg; results to *out_nll, out_grad[0..d),
-// *out_info (written by thread 0 / threads < d).  All POTRF_THREADS threads must call it; lds: SMALL_LDS_DOUBLES doubles.
-// The caller separates two calls (and its own reads of the outputs) by a barrier.
-// TG x TG threads hold the matrix as TS x TS register tiles: 16 x 16 threads with TS = 2 (n <= 32; TS = 4 up to 64 if the
-// caller asks for 256 threads there), 32 x 32 threads with TS = 2 / 4 for n <= 64 / 128 (WIDE: a 1024-thread workgroup,
-// which also gives the factor and inverse routines their 16 waves; the host uses it above 32 points).  With 8 x 8 tiles on 256 threads a 36-point problem kept 15 threads busy in the covariance build and the
-// gradient, a 94-point one 144.
-struct SmallLds {
-    double *Wl, *xs, *dg, *yv, *zv, *al, *r1, *r2, *red, *sc;
-    __device__ __forceinline__ explicit SmallLds(double* lds) {
-        Wl = lds;                         // [128][129]; first the packed L
-        xs = Wl + PB * SMALL_WP;          // [GRAD_D][128] inputs / theta
-        dg = xs + GRAD_D * PB;            // [128] diag L
-        yv = dg + PB;
-        zv = yv + PB;
-        al = zv + PB;
-        r1 = al + PB;                     // [128] reduction scratch: y_i alpha_i
-        r2 = r1 + PB;                     // [128] reduction scratch: log diag L
-        red = r2 + PB;                    // [16][GRAD_D] per-wave gradient partials
-        sc = red + 16 * GRAD_D;           // [0] y.alpha  [1] sum log diag L
-    }
-};
-
-// covariance tiles (identity pad beyond n) into the packed block, rows and columns < 16 TS
-template <int TS, int TG>
-__device__ __forceinline__ void lml_small_build(const SmallLds& m, int n, int d, double eps, int kernel) {
-    const int tid = threadIdx.x, tr = tid / TG, tc = tid % TG;
-#pragma unroll
-    for (int rr = 0; rr < TS; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < TS; ++cc) {
-            const int r = tr * TS + rr, c = tc * TS + cc;
-            if (c > r) continue;
-            double v = 0.0;
-            if (r == c) {
-                v = (r < n) ? 1.0 + eps : 1.0;
-            } else if (r < n) {
-                double D = 0.0;
-                for (int t = 0; t < d; ++t) {
-                    const double df = m.xs[t * PB + r] - m.xs[t * PB + c];
-                    D += df * df;
-                }
-                v = kern_eval(D, kernel);
-            }
-            m.Wl[tri_off(r) + c] = v;
-        }
-}
-
-// everything after the inverse: W out of the packed block, z, alpha, the scalars, Kinv = W^T W tile by tile, gradient sums
-template <int TS, int TG>
-__device__ __forceinline__ void lml_small_finish(const SmallLds& m, int n, int d, const double* th, int kernel, int want_grad,
-                                                 int fail, double* out_nll, double* out_grad, int* out_info) {
-    constexpr int MS = TG * TS;                // rows and columns covered by the register tiles
-    constexpr int NW = TG * TG / 64;           // waves
-    const int tid = threadIdx.x, tr = tid / TG, tc = tid % TG;
-    double* Wl = m.Wl;
-    const int nt = (n + TS - 1) / TS;          // tile columns that hold data; the rest of the block is the identity pad
-    double a[TS][TS];
-#pragma unroll
-    for (int rr = 0; rr < TS; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < TS; ++cc) {
-            const int r = tr * TS + rr, c = tc * TS + cc;
-            a[rr][cc] = (c <= r) ? Wl[tri_off(r) + (c <= r ? c : r)] : 0.0;
-        }
-    __syncthreads();                           // every read of the packed W is done
-#pragma unroll
-    for (int rr = 0; rr < TS; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < TS; ++cc) Wl[(tr * TS + rr) * SMALL_WP + tc * TS + cc] = a[rr][cc];
-    __syncthreads();
-    if (tid < PB) {                            // z = W y (row tid)
-        double z = 0.0;
-        if (tid < MS)
-            for (int c = 0; c <= min(tid, nt * TS - 1); ++c) z = fma(Wl[tid * SMALL_WP + c], m.yv[c], z);      // y is zero in the pad
-        m.zv[tid] = z;
-    }
-    __syncthreads();
-    if (tid < PB) {                            // alpha = W^T z (column tid)
-        double s = 0.0;
-        if (tid < MS)                          // beyond the register tiles the W space holds no matrix
-            for (int r = tid; r < nt * TS; ++r) s = fma(Wl[r * SMALL_WP + tid], m.zv[r], s);               // z is zero in the pad
-        m.al[tid] = s;
-        m.r1[tid] = m.yv[tid] * s;
-        m.r2[tid] = (tid < n) ? log(m.dg[tid]) : 0.0;
-    }
-    __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) {
-        if (tid < o) {
-            m.r1[tid] += m.r1[tid + o];
-            m.r2[tid] += m.r2[tid + o];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        m.sc[0] = m.r1[0];
-        m.sc[1] = m.r2[0];
-    }
-    __syncthreads();
-    const double ya = m.sc[0], sumlog = m.sc[1];
-    const double theta1 = ya / n;
-    const bool bad = fail >= 0;
-    if (tid == 0) {
-        const double nll = 0.5 * n * (log(2.0 * M_PI) + 1.0) + 0.5 * n * log(theta1) + sumlog;
-        *out_nll = bad ? NAN : nll;
-        *out_info = bad ? fail + 1 : 0;
-    }
-    if (!want_grad) return;
-    // Kinv tile (tr, tc), tr >= tc: sum over r >= TS tr of W[r][TS tr + rr] W[r][TS tc + cc] (W is zero above its diagonal)
-    const bool lower = tr >= tc;
-#pragma unroll
-    for (int rr = 0; rr < TS; ++rr)
-#pragma unroll
-        for (int cc = 0; cc < TS; ++cc) a[rr][cc] = 0.0;
-    if (lower && tr < nt) {                    // pad rows of W are rows of the identity: they add nothing for j, k < n
-        for (int r = tr * TS; r < nt * TS; ++r) {
-            double wj[TS], wk[TS];
-#pragma unroll
-            for (int t = 0; t < TS; ++t) {
-                wj[t] = Wl[r * SMALL_WP + tr * TS + t];
-                wk[t] = Wl[r * SMALL_WP + tc * TS + t];
-            }
-#pragma unroll
-            for (int rr = 0; rr < TS; ++rr)
-#pragma unroll
-                for (int cc = 0; cc < TS; ++cc) a[rr][cc] = fma(wj[rr], wk[cc], a[rr][cc]);
-        }
-        const double scale_c = (double)n / ya;
-        const double wgt = (tr == tc) ? 1.0 : 2.0;
-#pragma unroll
-        for (int rr = 0; rr < TS; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < TS; ++cc) {
-                const int j = tr * TS + rr, k = tc * TS + cc;
-                double c = 0.0;
-                if (j < n && k < n && j != k) {
-                    double D = 0.0;
-                    for (int t = 0; t < d; ++t) {
-                        const double df = m.xs[t * PB + j] - m.xs[t * PB + k];
-                        D += df * df;
-                    }
-                    c = wgt * (scale_c * m.al[j] * m.al[k] - a[rr][cc]) * kern_dfac(D, kernel);
-                }
-                a[rr][cc] = c;
-            }
-    }
-    for (int t = 0; t < d; ++t) {
-        double g = 0.0;
-        if (lower) {
-#pragma unroll
-            for (int rr = 0; rr < TS; ++rr)
-#pragma unroll
-                for (int cc = 0; cc < TS; ++cc) {
-                    const double df = m.xs[t * PB + tr * TS + rr] - m.xs[t * PB + tc * TS + cc];
-                    g = fma(a[rr][cc], df * df, g);
-                }
-        }
-        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o);
-        if ((tid & 63) == 0) m.red[(tid >> 6) * GRAD_D + t] = g;
-    }
-    __syncthreads();
-    if (tid < d) {
-        double sum = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; w += 4)
-            sum += (m.red[w * GRAD_D + tid] + m.red[(w + 1) * GRAD_D + tid]) + (m.red[(w + 2) * GRAD_D + tid] + m.red[(w + 3) * GRAD_D + tid]);
-        out_grad[tid] = bad ? NAN : -0.5 * sum * (1.0 / th[tid]);
-    }
-}
-
-template <bool WIDE>
-__device__ __forceinline__ void lml_small_body(double* __restrict__ lds, const double* __restrict__ Xraw, int xpitch,
-                                               const double* __restrict__ y, int n, int d, const double* th, double sg, int kernel,
-                                               int want_grad, double* out_nll, double* out_grad, int* out_info) {
-    const SmallLds m(lds);
-    const int tid = threadIdx.x;
-    const double eps = (sg == 0.0) ? 1e-15 * (double)n : sg * sg;
-    for (int idx = tid; idx < d * PB; idx += (WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS)) {
-        const int t = idx >> 7, i = idx & 127;
-        m.xs[idx] = (i < n) ? Xraw[(long)t * xpitch + i] * (1.0 / th[t]) : 0.0;
-    }
-    if (tid < PB) m.yv[tid] = (tid < n) ? y[tid] : 0.0;
-    __syncthreads();
-    // factor and inverse as in the diagonal-block kernel (register tile factorisation of the 16x16 tiles, everything
-    // else on MFMA), on the packed copy; the product buffer and the tile inverses live in the rest of the W space
-    __shared__ int fail_s;
-    double* Tbuf = m.Wl + POTRF_LDS_PACKED;
-    double* Wi8 = Tbuf + TRINV_T_DOUBLES;
-    static_assert(POTRF_LDS_PACKED + TRINV_T_DOUBLES + 8 * LEAF_DOUBLES <= PB * SMALL_WP, "scratch fits behind the packed block");
-    if (tid == 0) fail_s = -1;
-    if (WIDE && n > 64) lml_small_build<4, 32>(m, n, d, eps, kernel);
-    else if (WIDE) lml_small_build<2, 32>(m, n, d, eps, kernel);
-    else if (n <= 32) lml_small_build<2, 16>(m, n, d, eps, kernel);
-    else lml_small_build<4, 16>(m, n, d, eps, kernel);
-    __syncthreads();
-    const int ntl = (n + 15) >> 4;
-    potrf128_mfma(m.Wl, Wi8, &fail_s, ntl);
-    const int fail = fail_s;
-    if (tid < n) m.dg[tid] = m.Wl[tri_off(tid) + tid];
-    __syncthreads();                           // diag L is saved before the inverse overwrites it
-    trinv128_mfma(m.Wl, Wi8, Tbuf, ntl);
-    if (WIDE && n > 64) lml_small_finish<4, 32>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
-    else if (WIDE) lml_small_finish<2, 32>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
-    else if (n <= 32) lml_small_finish<2, 16>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
-    else lml_small_finish<4, 16>(m, n, d, th, kernel, want_grad, fail, out_nll, out_grad, out_info);
-}
-
-template <bool WIDE>
-__global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_lml_small(const double* __restrict__ Xraw, int xpitch,
-                                                             const double* __restrict__ y, int n, int d,
-                                                             const double* __restrict__ thetas,
-                                                             const double* __restrict__ sigmas, int kernel, int want_grad,
-                                                             double* __restrict__ out_nll, double* __restrict__ out_grad,
-                                                             int* __restrict__ out_info) {
-    __shared__ double lds[SMALL_LDS_DOUBLES];
-    const int b = blockIdx.x;
-    lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, thetas + (long)b * d, sigmas[b], kernel, want_grad, out_nll + b,
-                   out_grad + (long)b * d, out_info + b);
-}
-
-// The reference's descent on -logL (conj_gradient_descent, BayesOpt_v4.ipynb:31-87, steprule other than 'backtrack') for
-// n <= 128, one workgroup per start, every iteration inside the kernel: a multi-start fit is ONE launch instead of one
-// launch, two copies and a host round trip per iteration.  Per iteration k = 1 .. max_its, as the reference:
-//   dstep = (1 - beta) dtemp + beta dir(grad),  dir = sign(grad) sqrt(d) (norm 0, 'component'), grad / |grad| (1, 'full'), grad (2)
-//   wn = w - alpha dstep;  steprule 1 ('diminishing'): alpha = 1 / k from the next iteration on
-//   evaluate at wn: not positive definite -> record (wn, inf) and stop; else accept (w, grad, cost, dtemp = dstep), record,
-//   and stop with exitflag 1 once |wn - w| < 1e-10.
-// hist_w [(r (max_its + 1) + i) d + t], hist_c [r (max_its + 1) + i]: the iterates of start r and their costs (inf where the
-// matrix was not positive definite), count[r] of them; flag[r] the exit flag.  Update arithmetic without fused
-// multiply-adds, operation for operation as NumPy evaluates the reference's expressions (the host loop of the larger sizes).
-template <bool WIDE>
-__global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_descent_small(const double* __restrict__ Xraw, int xpitch,
-                                                                 const double* __restrict__ y, int n, int d,
-                                                                 const double* __restrict__ W0, double sg, int kernel, double alpha,
-                                                                 double beta, int norm, int steprule, int max_its,
-                                                                 double* __restrict__ hist_w, double* __restrict__ hist_c,
-                                                                 int* __restrict__ count, int* __restrict__ flag) {
-    __shared__ double lds[SMALL_LDS_DOUBLES];
-    __shared__ double w_s[GRAD_D], wn_s[GRAD_D], g_s[GRAD_D], gn_s[GRAD_D], dtemp_s[GRAD_D], dstep_s[GRAD_D];
-    __shared__ double nll_s, moved_s;
-    __shared__ int info_s, active_s, unusable_s;
-    const int tid = threadIdx.x, r = blockIdx.x;
-    const long H = (long)max_its + 1;
-    if (tid < d) {
-        w_s[tid] = W0[(long)r * d + tid];
-        dtemp_s[tid] = 0.0;
-    }
-    __syncthreads();
-    lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, w_s, sg, kernel, 1, &nll_s, g_s, &info_s);
-    __syncthreads();
-    if (tid < d) hist_w[(r * H) * d + tid] = w_s[tid];
-    if (tid == 0) {
-        hist_c[r * H] = (info_s == 0) ? nll_s : INFINITY;
-        active_s = (info_s == 0);
-        count[r] = 1;
-        flag[r] = 0;
-    }
-    __syncthreads();
-    double alpha_r = alpha;
-    int cnt = 1;
-    for (int k = 1; k <= max_its && active_s; ++k) {
-        if (tid == 0) {
-#pragma clang fp contract(off)                      // no fused multiply-adds here: every product and sum rounds as NumPy's does
-            // sums of squares in the order of NumPy's add.reduce over a contiguous axis (what np.linalg.norm(., axis=1) runs):
-            // below eight terms one after the other; from eight on, eight running sums over blocks of eight, joined as
-            // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the leftover terms one by one
-            double sqv[GRAD_D];
-            auto numpy_sum = [&](int m) {
-                if (m < 8) {
-                    double acc = 0.0;
-                    for (int t = 0; t < m; ++t) acc = acc + sqv[t];
-                    return acc;
-                }
-                double r8[8];
-                for (int j = 0; j < 8; ++j) r8[j] = sqv[j];
-                int i = 8;
-                for (; i < m - (m % 8); i += 8)
-                    for (int j = 0; j < 8; ++j) r8[j] = r8[j] + sqv[i + j];
-                double acc = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-                for (; i < m; ++i) acc = acc + sqv[i];
-                return acc;
-            };
-            double gnorm = 0.0;
-            if (norm == 1) {
-                for (int t = 0; t < d; ++t) sqv[t] = g_s[t] * g_s[t];
-                gnorm = sqrt(numpy_sum(d));
-            }
-            const double sqd = sqrt((double)d), omb = 1.0 - beta;
-            int unusable = 0;
-            for (int t = 0; t < d; ++t) {
-                const double g = g_s[t];
-                double dir;
-                if (norm == 0) {
-                    const double bs = beta * ((g != g) ? g : (double)((g > 0.0) - (g < 0.0)));
-                    dir = bs * sqd;
-                } else if (norm == 1) {
-                    const double gn = g / gnorm;
-                    dir = beta * gn;
-                } else {
-                    dir = beta * g;
-                }
-                const double mom = omb * dtemp_s[t];
-                const double ds = mom + dir;
-                const double stepv = alpha_r * ds;
-                const double wn = w_s[t] - stepv;
-                dstep_s[t] = ds;
-                wn_s[t] = wn;
-                const double df = wn - w_s[t];
-                sqv[t] = df * df;
-                unusable |= !(fabs(wn) < INFINITY) || wn == 0.0;
-            }
-            moved_s = sqrt(numpy_sum(d));
-            unusable_s = unusable;
-            if (unusable) info_s = 1;
-        }
-        if (steprule == 1) alpha_r = 1.0 / (double)k;
-        __syncthreads();
-        // an iterate that is not a set of finite, non-zero length scales (0/0 from a zero gradient under the 'full' norm, an
-        // overflow) is not evaluated: the start ends there like one whose matrix is not positive definite
-        if (!unusable_s) lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, wn_s, sg, kernel, 1, &nll_s, gn_s, &info_s);
-        __syncthreads();
-        const bool ok = info_s == 0;
-        if (tid < d) {
-            hist_w[(r * H + cnt) * d + tid] = wn_s[tid];
-            if (ok) {
-                w_s[tid] = wn_s[tid];
-                g_s[tid] = gn_s[tid];
-                dtemp_s[tid] = dstep_s[tid];
-            }
-        }
-        if (tid == 0) {
-            hist_c[r * H + cnt] = ok ? nll_s : INFINITY;
-            count[r] = cnt + 1;
-            if (!ok) active_s = 0;
-            else if (moved_s < 1e-10) {
-                flag[r] = 1;
-                active_s = 0;
-            }
-        }
-        cnt += 1;
-        __syncthreads();
-    }
-}
-
-// Sum of m <= GRAD_D terms in the order of NumPy's add.reduce over a contiguous axis: below eight terms one after the other;
-// from eight on, eight running sums over blocks of eight, joined as a tree, then the leftover terms one by one.
-__device__ __forceinline__ double numpy_order_sum(const double* v, int m) {
-#pragma clang fp contract(off)
-    if (m < 8) {
-        double acc = 0.0;
-        for (int t = 0; t < m; ++t) acc = acc + v[t];
-        return acc;
-    }
-    double r8[8];
-    for (int j = 0; j < 8; ++j) r8[j] = v[j];
-    int i = 8;
-    for (; i < m - (m % 8); i += 8)
-        for (int j = 0; j < 8; ++j) r8[j] = r8[j] + v[i + j];
-    double acc = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-    for (; i < m; ++i) acc = acc + v[i];
-    return acc;
-}
-
-// The 'backtrack' step rule of the same descent (BayesOpt_v4.ipynb:62-71), one workgroup per start, every trial point
-// evaluated inside the kernel.  Per outer iteration, as the reference:
-//   wtemp = w;  w = w - alpha d;  h = g(wtemp) + grad(wtemp).(w - wtemp) + |w - wtemp|^2 / (2 alpha)
-//   while g(w) > h (at most 200 rounds):  alpha *= 0.8;  w = w - alpha d;  h = (the same expression: old wtemp, new alpha);  wtemp = w
-//   w = w - alpha d            (one more step after the loop; alpha stays shrunk for the following iterations)
-// A trial point whose matrix is not positive definite, or that is no longer a set of finite non-zero length scales, ends the
-// start: the iterate after the closing step is recorded with cost +inf.  The walk is a three-phase state machine (0 first
-// trial, 1 a round of the shrinking loop, 2 the closing step) around ONE evaluation site; thread 0 keeps the books without
-// fused multiply-adds, in the order NumPy evaluates the expressions above over a batch of starts.
-template <bool WIDE>
-__global__ __launch_bounds__(WIDE ? SMALL_WIDE_THREADS : POTRF_THREADS) void k_descent_backtrack_small(
-    const double* __restrict__ Xraw, int xpitch, const double* __restrict__ y, int n, int d, const double* __restrict__ W0, double sg,
-    int kernel, double alpha, double beta, int norm, int max_its, double* __restrict__ hist_w, double* __restrict__ hist_c,
-    int* __restrict__ count, int* __restrict__ flag) {
-    __shared__ double lds[SMALL_LDS_DOUBLES];
-    __shared__ double w_s[GRAD_D], wn_s[GRAD_D], g_s[GRAD_D], gn_s[GRAD_D], dtemp_s[GRAD_D], dstep_s[GRAD_D], wt_s[GRAD_D], gt_s[GRAD_D];
-    __shared__ double nll_s, cost_s, ft_s, h_s, alpha_s;
-    __shared__ int info_s, active_s, eval_s, phase_s, failed_s, rounds_s, k_s, cnt_s;
-    const int tid = threadIdx.x, r = blockIdx.x;
-    const long H = (long)max_its + 1;
-    if (tid < d) {
-        w_s[tid] = W0[(long)r * d + tid];
-        dtemp_s[tid] = 0.0;
-    }
-    __syncthreads();
-    lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, w_s, sg, kernel, 1, &nll_s, g_s, &info_s);
-    __syncthreads();
-    if (tid < d) hist_w[(r * H) * d + tid] = w_s[tid];
-    if (tid == 0) {
-        cost_s = (info_s == 0) ? nll_s : INFINITY;
-        hist_c[r * H] = cost_s;
-        active_s = (info_s == 0) && max_its >= 1;
-        count[r] = 1;
-        flag[r] = 0;
-        alpha_s = alpha;
-        phase_s = 0;
-        k_s = 1;
-        cnt_s = 1;
-    }
-    __syncthreads();
-    while (active_s) {
-        if (tid == 0) {
-#pragma clang fp contract(off)
-            double sqv[GRAD_D];
-            const int phase = phase_s;
-            if (phase == 0) {
-                double gnorm = 0.0;
-                if (norm == 1) {
-                    for (int t = 0; t < d; ++t) sqv[t] = g_s[t] * g_s[t];
-                    gnorm = sqrt(numpy_order_sum(sqv, d));
-                }
-                const double sqd = sqrt((double)d), omb = 1.0 - beta;
-                for (int t = 0; t < d; ++t) {
-                    const double g = g_s[t];
-                    double dir;
-                    if (norm == 0) {
-                        const double bs = beta * ((g != g) ? g : (double)((g > 0.0) - (g < 0.0)));
-                        dir = bs * sqd;
-                    } else if (norm == 1) {
-                        const double gn = g / gnorm;
-                        dir = beta * gn;
-                    } else {
-                        dir = beta * g;
-                    }
-                    const double mom = omb * dtemp_s[t];
-                    dstep_s[t] = mom + dir;
-                    wt_s[t] = w_s[t];
-                    gt_s[t] = g_s[t];
-                    wn_s[t] = w_s[t];
-                }
-                ft_s = cost_s;
-                failed_s = 0;
-                rounds_s = 0;
-            } else if (phase == 1) {
-                alpha_s = alpha_s * 0.8;
-            }
-            const double a = alpha_s;
-            int unusable = 0;
-            for (int t = 0; t < d; ++t) {
-                const double stepv = a * dstep_s[t];
-                const double wn = wn_s[t] - stepv;
-                wn_s[t] = wn;
-                unusable |= !(fabs(wn) < INFINITY) || wn == 0.0;
-            }
-            if (phase == 1) {                   // the bound the coming evaluation is held against: old wtemp, its cost and gradient
-                for (int t = 0; t < d; ++t) {
-                    const double df = wn_s[t] - wt_s[t];
-                    sqv[t] = gt_s[t] * df;
-                }
-                const double s1 = numpy_order_sum(sqv, d);
-                for (int t = 0; t < d; ++t) {
-                    const double df = wn_s[t] - wt_s[t];
-                    sqv[t] = df * df;
-                }
-                const double s2 = numpy_order_sum(sqv, d);
-                const double two_a = 2.0 * a;
-                h_s = (ft_s + s1) + s2 / two_a;
-            }
-            const int skip = unusable || (phase == 2 && failed_s);
-            if (unusable) failed_s = 1;
-            eval_s = !skip;
-            info_s = skip ? 1 : 0;
-        }
-        __syncthreads();
-        // the gradient at the first trial point is never used (either the loop replaces it or the closing step moves on)
-        if (eval_s) lml_small_body<WIDE>(lds, Xraw, xpitch, y, n, d, wn_s, sg, kernel, phase_s != 0, &nll_s, gn_s, &info_s);
-        __syncthreads();
-        if (tid == 0) {
-#pragma clang fp contract(off)
-            double sqv[GRAD_D];
-            const int phase = phase_s;
-            const bool bad = info_s != 0;
-            if (phase == 0) {
-                if (bad) {
-                    failed_s = 1;
-                    phase_s = 2;
-                } else {
-                    for (int t = 0; t < d; ++t) {
-                        const double df = wn_s[t] - wt_s[t];
-                        sqv[t] = gt_s[t] * df;
-                    }
-                    const double s1 = numpy_order_sum(sqv, d);
-                    for (int t = 0; t < d; ++t) {
-                        const double df = wn_s[t] - wt_s[t];
-                        sqv[t] = df * df;
-                    }
-                    const double s2 = numpy_order_sum(sqv, d);
-                    const double two_a = 2.0 * alpha_s;
-                    h_s = (ft_s + s1) + s2 / two_a;
-                    phase_s = (nll_s > h_s) ? 1 : 2;
-                }
-            } else if (phase == 1) {
-                rounds_s += 1;
-                if (bad) {
-                    failed_s = 1;
-                    phase_s = 2;
-                } else {
-                    for (int t = 0; t < d; ++t) {
-                        wt_s[t] = wn_s[t];
-                        gt_s[t] = gn_s[t];
-                    }
-                    ft_s = nll_s;
-                    phase_s = (nll_s > h_s && rounds_s < 200) ? 1 : 2;
-                }
-            } else {
-                const int cnt = cnt_s;
-                for (int t = 0; t < d; ++t) hist_w[(r * H + cnt) * d + t] = wn_s[t];
-                if (failed_s || bad) {
-                    hist_c[r * H + cnt] = INFINITY;
-                    active_s = 0;
-                } else {
-                    for (int t = 0; t < d; ++t) {
-                        const double df = wn_s[t] - w_s[t];
-                        sqv[t] = df * df;
-                    }
-                    const double moved = sqrt(numpy_order_sum(sqv, d));
-                    for (int t = 0; t < d; ++t) {
-                        w_s[t] = wn_s[t];
-                        g_s[t] = gn_s[t];
-                        dtemp_s[t] = dstep_s[t];
-                    }
-                    cost_s = nll_s;
-                    hist_c[r * H + cnt] = nll_s;
-                    if (moved < 1e-10) {
-                        flag[r] = 1;
-                        active_s = 0;
-                    }
-                }
-                count[r] = cnt + 1;
-                cnt_s = cnt + 1;
-                k_s += 1;
-                if (k_s > max_its) active_s = 0;
-                phase_s = 0;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// Per-lane device slot of the likelihood sweep: everything that changes from one setting to the next reaches the
-// kernels through it, so the launch sequence of a setting has constant arguments and can be replayed from a graph.
-struct LmlSlot {
-    double theta[MAX_D];
-    double eps;
-    int cur;      // index of the setting in the batch
-    int info;     // factorisation status of this setting
-};
-static_assert(sizeof(LmlSlot) % sizeof(double) == 0, "slots are strided in doubles");
-
-__global__ void k_pick_setting(int b0, int B, const double* __restrict__ thetas, const double* __restrict__ sigmas, int d, int n,
-                               LmlSlot* __restrict__ slots) {
-    // slot blockIdx.x takes setting b0 + blockIdx.x; past the end of the batch it recomputes the last setting and is
-    // marked inactive (cur = -1: nothing is stored for it)
-    LmlSlot* slot = slots + blockIdx.x;
-    const int bq = b0 + blockIdx.x;
-    const int b = bq < B ? bq : B - 1;
-    const int t = threadIdx.x;
-    if (t < d) slot->theta[t] = thetas[(long)b * d + t];
-    if (t == 0) {
-        const double sg = sigmas[b];
-        slot->eps = (sg == 0.0) ? 1e-15 * (double)n : sg * sg;
-        slot->cur = bq < B ? bq : -1;
-        slot->info = 0;
-    }
-}
-
-// every slot's observation vector is the same padded y: dst[s*n_pad + i] = src[i], s = blockIdx.y
-__global__ __launch_bounds__(256) void k_replicate_vec(const double* __restrict__ src, double* __restrict__ dst, int n_pad) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_pad) dst[(long)blockIdx.y * n_pad + i] = src[i];
-}
-
-// b = slot->cur: out_nll[b] = -logL (NaN when the factorisation failed), out_grad[b*d + t] = -1/2 * sum_tiles gpart / theta_t,
-// out_info[b] = the factorisation status
-__global__ __launch_bounds__(256) void k_lml_store(const double* __restrict__ params, const LmlSlot* __restrict__ slot,
-                                                   const double* __restrict__ gpart, int ntiles, int d, int want_grad,
-                                                   double* __restrict__ out_nll, double* __restrict__ out_grad,
-                                                   int* __restrict__ out_info, BatchStride bs) {
-    __shared__ double r[256];
-    params += blockIdx.z * bs.par;
-    slot += blockIdx.z;
-    gpart += blockIdx.z * bs.gp;
-    const int tid = threadIdx.x;
-    const int b = slot->cur;
-    if (b < 0) return;
-    const bool bad = (slot->info != 0);
-    if (tid == 0) {
-        out_nll[b] = bad ? NAN : params[P_NLL];
-        out_info[b] = slot->info;
-    }
-    if (!want_grad) return;
-    for (int t = 0; t < d; ++t) {
-        double s = 0.0;
-        for (int i = tid; i < ntiles; i += 256) s += gpart[(long)i * GRAD_D + t];
-        r[tid] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) r[tid] += r[tid + o];
-            __syncthreads();
-        }
-        if (tid == 0) out_grad[(long)b * d + t] = bad ? NAN : -0.5 * r[0] * params[P_INVTHETA + t];
-        __syncthreads();
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------
-// Incremental append of one training point (single-factor variant, theta frozen).
-// scal (device doubles): [0] d_new  [1] z_new  [2] ll = l.l  [3] lz = l.z
-enum { A_DNEW = 0, A_ZNEW = 1, A_LL = 2, A_LZ = 3 };
-
-// kvec[i] = k(x_i, x_new) for i < n (0 for the pad); also records the new scaled point as column n of Xts.
-// First launch of a loop step: the new scaled point arrives as a kernel argument and is left in device memory (xnew_out)
-// for the kernels that follow, and the status word is cleared -- no launch, copy or fill of their own for either.
-__device__ __forceinline__ void append_kvec_at(int i, double* __restrict__ Xts, int n, int n_pad, int d, const PointArg& p,
-                                               double* __restrict__ xnew_out, int* __restrict__ info, double* __restrict__ kvec,
-                                               int kernel) {
-    if (i < MAX_D) xnew_out[i] = p.x[i];
-    if (i == 0) *info = 0;
-    if (i >= n_pad) return;
-    double v = 0.0;
-    if (i < n) {
-        double Dq = 0.0;
-        for (int t = 0; t < d; ++t) {
-            const double df = Xts[(long)t * n_pad + i] - p.x[t];
-            Dq += df * df;
-        }
-        v = kern_eval(Dq, kernel);
-    }
-    kvec[i] = v;
-    if (i == n)
-        for (int t = 0; t < d; ++t) Xts[(long)t * n_pad + n] = p.x[t];
-}
-
-__global__ __launch_bounds__(256) void k_append_kvec(double* __restrict__ Xts, int n, int n_pad, int d, PointArg p,
-                                                     double* __restrict__ xnew_out, int* __restrict__ info,
-                                                     double* __restrict__ kvec, int kernel) {
-    append_kvec_at(blockIdx.x * 256 + threadIdx.x, Xts, n, n_pad, d, p, xnew_out, info, kvec, kernel);
-}
-
-// l = W[0:n,0:n] * kvec  (one wave per row, lanes along the row)
-__device__ __forceinline__ void append_lvec_row(int row, int lane, const double* __restrict__ W, long ld, int n,
-                                                const double* __restrict__ kvec, double* __restrict__ lvec) {
-    if (row >= n) return;
-    double s = 0.0;
-    for (int j = lane; j <= row; j += 64) s += W[(long)row * ld + j] * kvec[j];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) lvec[row] = s;
-}
-
-// Four rows (row0, row0 + 16, row0 + 32, row0 + 48) by one wave, their loads in flight together: for a single workgroup walking
-// over all rows the time is the number of memory round trips.  Each row's sum is formed exactly as in append_lvec_row.
-__device__ __forceinline__ void append_lvec_rows4(int row0, int lane, const double* __restrict__ W, long ld, int n,
-                                                  const double* __restrict__ kvec, double* __restrict__ lvec) {
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-    const int last = (row0 + 48 < n ? row0 + 48 : n - 1);
-    for (int j = lane; j <= last; j += 64) {
-        const double kj = kvec[j];
-        double wv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = row0 + 16 * u;
-            wv[u] = (row < n && j <= row) ? W[(long)row * ld + j] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = row0 + 16 * u;
-            if (row < n && j <= row) s[u] += wv[u] * kj;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        double t = s[u];
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-        if (lane == 0 && row0 + 16 * u < n) lvec[row0 + 16 * u] = t;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_append_lvec(const double* __restrict__ W, long ld, int n, const double* __restrict__ kvec,
-                                                     double* __restrict__ lvec) {
-    append_lvec_row(blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, W, ld, n, kvec, lvec);
-}
-
-// One workgroup: d_new = sqrt(1 + eps - l.l), z_new = (y_new - l.z)/d_new, scalars of the enlarged model,
-// new rows of L (optional) and the diagonal of W.  n is the size BEFORE the append.
-// (tid < 256 and `active`: the 256 threads that do the work; every thread of the workgroup calls it, for the barriers)
-__device__ __forceinline__ void append_scalars_phase(int tid, bool active, double* r1, double* r2, const double* __restrict__ lvec,
-                                                     double* __restrict__ zfw, double* __restrict__ yv, int n, double y_new, double eps,
-                                                     double* __restrict__ scal, double* __restrict__ params, double* __restrict__ L,
-                                                     double* __restrict__ W, long ld, int* __restrict__ info) {
-    double ll = 0.0, lz = 0.0;
-    if (active) {
-        for (int i = tid; i < n; i += 256) {
-            ll += lvec[i] * lvec[i];
-            lz += lvec[i] * zfw[i];
-        }
-        r1[tid] = ll;
-        r2[tid] = lz;
-    }
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (active && tid < o) {
-            r1[tid] += r1[tid + o];
-            r2[tid] += r2[tid + o];
-        }
-        __syncthreads();
-    }
-    if (!active) return;
-    const double dd = 1.0 + eps - r1[0];
-    const double dnew = sqrt(dd);
-    const double znew = (y_new - r2[0]) / dnew;
-    if (L)
-        for (int i = tid; i < n; i += 256) L[(long)n * ld + i] = lvec[i];
-    if (tid == 0) {
-        if (!(dd > 0.0)) atomicCAS(info, 0, n + 1);
-        scal[A_DNEW] = dnew;
-        scal[A_ZNEW] = znew;
-        scal[A_LL] = r1[0];
-        scal[A_LZ] = r2[0];
-        zfw[n] = znew;
-        yv[n] = y_new;
-        if (L) L[(long)n * ld + n] = dnew;
-        W[(long)n * ld + n] = 1.0 / dnew;
-        const int n1 = n + 1;
-        const double ya = params[P_YA] + znew * znew;          // y^T K^-1 y = |L^-1 y|^2
-        const double sumlog = params[P_SUMLOG] + log(dnew);
-        const double theta1 = ya / n1;
-        params[P_YA] = ya;
-        params[P_SUMLOG] = sumlog;
-        params[P_THETA1] = theta1;
-        params[P_C0] = theta1;
-        params[P_C1] = theta1;
-        params[P_YMAX] = fmax(params[P_YMAX], y_new);
-        params[P_NLL] = 0.5 * n1 * (log(2.0 * M_PI) + 1.0) + 0.5 * n1 * log(theta1) + sumlog;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_append_scalars(const double* __restrict__ lvec, double* __restrict__ zfw,
-                                                        double* __restrict__ yv, int n, double y_new, double eps,
-                                                        double* __restrict__ scal, double* __restrict__ params,
-                                                        double* __restrict__ L, double* __restrict__ W, long ld,
-                                                        int* __restrict__ info) {
-    __shared__ double r1[256];
-    __shared__ double r2[256];
-    append_scalars_phase(threadIdx.x, true, r1, r2, lvec, zfw, yv, n, y_new, eps, scal, params, L, W, ld, info);
-}
-
-// New row of W and the enlarged alpha, per column j <= n (n = size before the append):
-//   W[n][j] = -(1/d_new) * sum_{i=j..n-1} l_i W[i][j]  (j < n; W[n][n] is already in place),
-//   alpha1[j] = alpha[j] = sum_{i=j..n} W[i][j] z_i   (W^T z over the enlarged model; the mean of this variant uses alpha = alpha1).
-// Both sums are always formed as eight partial sums over (i - j) mod 8, joined pairwise -- by one thread here, by eight
-// threads in k_append_wrow: the same arithmetic, so the two routes of an append update the factor bit for bit alike.
-__device__ __forceinline__ double join8(const double (&p)[8]) { return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])); }
-
-// Neither result is read by the sweep over the candidates, so the first workgroup(s) of the streaming sweep's launch run
-// this routine beside it instead of launches of their own in front of it.
-__device__ __forceinline__ void append_wrow_alpha(int blk, double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
-                                                  const double* __restrict__ scal, const double* __restrict__ zfw,
-                                                  double* __restrict__ alpha1, double* __restrict__ alpha) {
-    const int j = blk * 256 + threadIdx.x;
-    if (j > n) return;
-    double a = 0.0, wn;
-    if (j < n) {
-        double ps[8], pa[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ps[q] = pa[q] = 0.0;
-        int i = j;
-        for (; i + 8 <= n; i += 8) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double w = W[(long)(i + q) * ld + j];
-                ps[q] = fma(lvec[i + q], w, ps[q]);
-                pa[q] = fma(w, zfw[i + q], pa[q]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (i + q < n) {
-                const double w = W[(long)(i + q) * ld + j];
-                ps[q] = fma(lvec[i + q], w, ps[q]);
-                pa[q] = fma(w, zfw[i + q], pa[q]);
-            }
-        wn = -join8(ps) / scal[A_DNEW];
-        a = join8(pa);
-        W[(long)n * ld + j] = wn;
-    } else {
-        wn = W[(long)n * ld + n];
-    }
-    a = fma(wn, zfw[n], a);
-    alpha1[j] = a;
-    alpha[j] = a;
-}
-
-// The same update in a launch of its own (the lattice route of an append has no streaming sweep to ride along with): 32
-// columns x 8 threads per workgroup, thread q of a column forms partial sum q.
-// (blk < 0: a thread group with no columns of its own, there for the barrier only)
-__device__ __forceinline__ void append_wrow_block(int blk, int t256, double (*ss)[33], double (*sa)[33], double* __restrict__ W, long ld,
-                                                  int n, const double* __restrict__ lvec, const double* __restrict__ scal,
-                                                  const double* __restrict__ zfw, double* __restrict__ alpha1,
-                                                  double* __restrict__ alpha) {
-    const int c = t256 & 31, q = t256 >> 5;
-    const int j = blk < 0 ? n + 1 : blk * 32 + c;
-    double ps = 0.0, pa = 0.0;
-    if (j < n) {
-        int i = j + q;
-        for (; i + 24 < n; i += 32) {        // four loads in flight; the sums in the same order as one at a time
-            double w4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) w4[u] = W[(long)(i + 8 * u) * ld + j];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ps = fma(lvec[i + 8 * u], w4[u], ps);
-                pa = fma(w4[u], zfw[i + 8 * u], pa);
-            }
-        }
-        for (; i < n; i += 8) {
-            const double w = W[(long)i * ld + j];
-            ps = fma(lvec[i], w, ps);
-            pa = fma(w, zfw[i], pa);
-        }
-    }
-    ss[q][c] = ps;
-    sa[q][c] = pa;
-    __syncthreads();
-    if (q != 0 || j > n) return;
-    double a = 0.0, wn;
-    if (j < n) {
-        const double s8[8] = {ss[0][c], ss[1][c], ss[2][c], ss[3][c], ss[4][c], ss[5][c], ss[6][c], ss[7][c]};
-        const double a8[8] = {sa[0][c], sa[1][c], sa[2][c], sa[3][c], sa[4][c], sa[5][c], sa[6][c], sa[7][c]};
-        wn = -join8(s8) / scal[A_DNEW];
-        a = join8(a8);
-        W[(long)n * ld + j] = wn;
-    } else {
-        wn = W[(long)n * ld + n];
-    }
-    a = fma(wn, zfw[n], a);
-    alpha1[j] = a;
-    alpha[j] = a;
-}
-
-__global__ __launch_bounds__(256) void k_append_wrow(double* __restrict__ W, long ld, int n, const double* __restrict__ lvec,
-                                                     const double* __restrict__ scal, const double* __restrict__ zfw,
-                                                     double* __restrict__ alpha1, double* __restrict__ alpha) {
-    __shared__ double ss[8][33], sa[8][33];
-    append_wrow_block((int)blockIdx.x, threadIdx.x, ss, sa, W, ld, n, lvec, scal, zfw, alpha1, alpha);
-}
-
-// The HBM-streaming sweep: per candidate j
-//   v = (k(xs_j, x_new) - sum_{k<n} l_k V[k][j]) / d_new ;  V[n][j] = v ;  s_j += v^2 ;  mu_j += v z_new ;
-//   var_j = theta1 (1 - s_j), < 1e-60 -> 0.
-// A thread owns VEC adjacent candidates (VEC = 2: 16-byte loads, 1 KiB per wave instruction; needs m even) and keeps
-// eight rows of V in flight; V is read once and never again, so the loads are non-temporal.  The dot product of a
-// candidate is always eight partial sums over k mod 8, combined pairwise: the same arithmetic in both forms, so a
-// candidate's result does not depend on how the set is split over ranks.
-template <int D, int VEC>
-__global__ __launch_bounds__(256) void k_append_sweep(const double* __restrict__ Xs, long m, int d_rt,
-                                                      const double* __restrict__ xnew, const double* __restrict__ params,
-                                                      const double* __restrict__ lvec, const double* __restrict__ scal,
-                                                      double* __restrict__ V, long ldv, int n, double* __restrict__ sres,
-                                                      double* __restrict__ mu, double* __restrict__ var, int kernel,
-                                                      double* __restrict__ bmax, int extra, double* __restrict__ W, long ldw,
-                                                      const double* __restrict__ zfw, double* __restrict__ alpha1,
-                                                      double* __restrict__ alpha) {
-    // the first `extra` workgroups complete the factor update (new row of W, alpha); the others stream V
-    if ((int)blockIdx.x < extra) {
-        append_wrow_alpha((int)blockIdx.x, W, ldw, n, lvec, scal, zfw, alpha1, alpha);
-        return;
-    }
-    const long blk = (long)blockIdx.x - extra;
-    const long j = (blk * 256 + threadIdx.x) * VEC;
-    double mx = -INFINITY;           // the largest updated mean among this thread's candidates
-    if (j < m) {
-    const int d = (D > 0) ? D : d_rt;
-    double dot[VEC][8];
-#pragma unroll
-    for (int c = 0; c < VEC; ++c)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) dot[c][u] = 0.0;
-    const double* Vj = V + j;
-    int k = 0;
-    for (; k + 8 <= n; k += 8) {
-        double vv[8][VEC];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (VEC == 2) {
-                const f64x2 t = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(Vj + (long)(k + u) * ldv));
-                vv[u][0] = t.x;
-                vv[u][VEC - 1] = t.y;
-            } else {
-                vv[u][0] = __builtin_nontemporal_load(Vj + (long)(k + u) * ldv);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double l = lvec[k + u];
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) dot[c][u] = fma(l, vv[u][c], dot[c][u]);
-        }
-    }
-    for (int u = 0; k < n; ++k, ++u) {
-        const double l = lvec[k];
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            const double t = Vj[(long)k * ldv + c];
-#pragma unroll
-            for (int w = 0; w < 8; ++w)
-                if (w == u) dot[c][w] = fma(l, t, dot[c][w]);
-        }
-    }
-    const double dnew = scal[A_DNEW], znew = scal[A_ZNEW];
-    const double c0 = params[P_C0], c1 = params[P_C1];
-    double vout[VEC];
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-        double Dq = 0.0;
-#pragma unroll
-        for (int t = 0; t < ((D > 0) ? D : MAX_D); ++t)
-            if (t < d) {
-                const double df = Xs[(j + c) * d + t] * params[P_INVTHETA + t] - xnew[t];
-                Dq += df * df;
-            }
-        const double sum = ((dot[c][0] + dot[c][1]) + (dot[c][2] + dot[c][3])) + ((dot[c][4] + dot[c][5]) + (dot[c][6] + dot[c][7]));
-        const double v = (kern_eval(Dq, kernel) - sum) / dnew;
-        vout[c] = v;
-        const double s = sres[j + c] + v * v;
-        sres[j + c] = s;
-        const double mnew = mu[j + c] + v * znew;
-        mu[j + c] = mnew;
-        mx = max_nan(mx, mnew);
-        double vr = c0 - c1 * s;
-        if (vr < 1e-60) vr = 0.0;
-        var[j + c] = vr;
-    }
-    if (VEC == 2) {
-        f64x2 t;
-        t.x = vout[0];
-        t.y = vout[VEC - 1];
-        *reinterpret_cast<f64x2*>(V + (long)n * ldv + j) = t;
-    } else {
-        V[(long)n * ldv + j] = vout[0];
-    }
-    }
-    // max(mu) of the workgroup's candidates (stage 1 of the reduction every iteration needs, free of a pass over mu)
-    __shared__ double wm[4];
-    for (int o = 32; o > 0; o >>= 1) mx = max_nan(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) bmax[blk] = max_nan(max_nan(wm[0], wm[1]), max_nan(wm[2], wm[3]));
-}
-
-
-// u = W v  (lower-triangular W, wave per row) and x = W^T u (thread per column), for q vectors stored
-// column-after-column with pitch n_pad:  K^-1 v = W^T (W v).
-__global__ __launch_bounds__(256) void k_tri_gemv_n(const double* __restrict__ W, long ld, int n, const double* __restrict__ v,
-                                                    double* __restrict__ u, int n_pad) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.y;
-    if (row >= n) return;
-    double s = 0.0;
-    for (int j = lane; j <= row; j += 64) s += W[(long)row * ld + j] * v[(long)q * n_pad + j];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) u[(long)q * n_pad + row] = s;
-}
-__global__ __launch_bounds__(256) void k_tri_gemv_t(const double* __restrict__ W, long ld, int n, const double* __restrict__ u,
-                                                    double* __restrict__ x, int n_pad) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int q = blockIdx.y;
-    if (j >= n) return;
-    double s = 0.0;
-    for (int i = j; i < n; ++i) s += W[(long)i * ld + j] * u[(long)q * n_pad + i];
-    x[(long)q * n_pad + j] = s;
-}
-
-
-// K[i][j] = k(U_i, V_j) for two arbitrary point sets (row-major (p,d), (q,d)); direct differences.
-__global__ __launch_bounds__(256) void k_cross_kernel(const double* __restrict__ U, long p, const double* __restrict__ V, long q,
-                                                      int d, const double* __restrict__ invtheta, int kernel,
-                                                      double* __restrict__ K) {
-    const long j = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const long i = (long)blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= p || j >= q) return;
-    double D = 0.0;
-    for (int t = 0; t < d; ++t) {
-        const double df = (U[i * d + t] - V[j * d + t]) * invtheta[t];
-        D += df * df;
-    }
-    K[i * q + j] = kern_eval(D, kernel);
-}
-
-// kernfcn_v2 on explicit per-dimension |difference| matrices (the notebooks' Daa list): Dabs is [d][p*q].
-__global__ __launch_bounds__(256) void k_kernel_from_absdiff(const double* __restrict__ Dabs, long pq, int d,
-                                                             const double* __restrict__ invtheta, int kernel,
-                                                             double* __restrict__ K) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= pq) return;
-    double D = 0.0;
-    for (int t = 0; t < d; ++t) {
-        const double df = Dabs[(long)t * pq + e] * invtheta[t];
-        D += df * df;
-    }
-    K[e] = kern_eval(D, kernel);
-}
-
-// out[0] = min, out[1] = max of diag(L), rows < n.  One workgroup.
-__global__ __launch_bounds__(256) void k_diag_minmax(const double* __restrict__ L, long ld, int n, double* __restrict__ out) {
-    __shared__ double lo[256], hi[256];
-    const int tid = threadIdx.x;
-    double a = INFINITY, b = -INFINITY;
-    for (int i = tid; i < n; i += 256) {
-        const double v = L[(long)i * ld + i];
-        a = fmin(a, v);
-        b = fmax(b, v);
-    }
-    lo[tid] = a;
-    hi[tid] = b;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            lo[tid] = fmin(lo[tid], lo[tid + o]);
-            hi[tid] = fmax(hi[tid], hi[tid + o]);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        out[0] = lo[0];
-        out[1] = hi[0];
-    }
-}
-
-// Synthetic candidates: element e of the row-major (m, d) set is the counter-based splitmix64 stream
-//   u(seed, e0 + e) = (mix(seed, e0 + e) >> 11) * 2^-53  in [0, 1),
-// integer arithmetic and an exact conversion, so a shard generated here is bit-identical to the same rows generated
-// on the host.  count = m * d elements.
-__global__ __launch_bounds__(256) void k_uniform_splitmix(double* __restrict__ out, long count, unsigned long long seed,
-                                                          unsigned long long e0) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
-    unsigned long long z = (e0 + (unsigned long long)e + 1ull) * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    out[e] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
-}
-
-__global__ void k_set_scalar(double* dst, double v) { *dst = v; }
-__global__ void k_copy_scalar(double* dst, const double* src) { *dst = *src; }
-__global__ void k_copy4(double* dst, const double* src) {
-    if (threadIdx.x < 4) dst[threadIdx.x] = src[threadIdx.x];
-}
-
 }  // namespace gpbo
+
+#include "k_covariance.hpp"
+#include "k_cholesky.hpp"
+#include "k_inverse.hpp"
+#include "k_trsv.hpp"
+#include "k_posterior.hpp"
+#include "k_acquisition.hpp"
+#include "k_lml.hpp"
+#include "k_append.hpp"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Coefficients of erfcx_over_t (bayesian_optimization_amd/csrc/kernels.hpp): the Chebyshev series of
+"""Coefficients of erfcx_over_t (bayesian_optimization_amd/csrc/k_acquisition.hpp): the Chebyshev series of
     G(u) = exp(z^2) erfc(z) / t,   t = 2 / (2 + z),   u = 2 t - 1 in (-1, 1]   (z = 0 at u = 1, z = inf at u = -1)
 projected at 96 Chebyshev nodes in 60-digit arithmetic, truncated to 28 terms; prints the truncation error over a grid
 and the table as it stands in the source.      python3 scripts/erfcx_chebyshev.py   (build container: needs mpmath)"""

@@ -40,7 +40,7 @@ int main() {
             float ms[4];
             hipEvent_t ev[5]; for (auto& e : ev) (void)hipEventCreate(&e);
             (void)hipEventRecord(ev[0], P);
-            for (int p = 0; p < 4; ++p) { k_potrf_diag<false><<<1, POTRF_THREADS, 0, P>>>(A, ld, p, Dinv, info, BatchStride{}, 0, 1 << 20); (void)hipEventRecord(ev[p + 1], P); }
+            for (int p = 0; p < 4; ++p) { k_potrf_diag<<<1, POTRF_MFMA_THREADS, 0, P>>>(A, ld, p, Dinv, info, BatchStride{}, 0, 1 << 20); (void)hipEventRecord(ev[p + 1], P); }
             (void)hipDeviceSynchronize();
             for (int p = 0; p < 4; ++p) (void)hipEventElapsedTime(&ms[p], ev[p], ev[p + 1]);
             float bms = 0; if (leave_out >= 0) (void)hipEventElapsedTime(&bms, b0, b1);

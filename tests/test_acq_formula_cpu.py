@@ -1,4 +1,4 @@
-"""CPU: the coefficient table of the acquisition kernels' complementary error function (erfcx_over_t in csrc/kernels.hpp),
+"""CPU: the coefficient table of the acquisition kernels' complementary error function (erfcx_over_t in csrc/k_acquisition.hpp),
 read from the source and evaluated with the kernel's own arithmetic in NumPy, against scipy's ndtr (what the reference's
 norm.cdf calls, BayesOpt_v4.ipynb:194) and against the reference's EI formula."""
 import os
@@ -12,7 +12,7 @@ from oracle import gp_oracle as o
 
 
 def table():
-    src = open(os.path.join(ROOT, 'bayesian_optimization_amd', 'csrc', 'kernels.hpp')).read()
+    src = open(os.path.join(ROOT, 'bayesian_optimization_amd', 'csrc', 'k_acquisition.hpp')).read()
     blk = src[src.index('constexpr double c[28] = {'):]
     c = np.array([float(x) for x in re.sub(r'\s+', ' ', blk[blk.index('{') + 1:blk.index('}')]).split(',')])
     assert c.shape == (28,)
