@@ -892,8 +892,16 @@ int acquire_enqueue(gpbo_ctx* ctx, int acq, double kappa, int mode, double incum
         hipLaunchKernelGGL(k_acquire_argmax<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, vsrc,
                            (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi, inc_parts, n_parts,
                            ctx->inc_dev, c01);
+    else if (acq == GPBO_ACQ_EI)      // the loop's pass, one instantiation per acquisition: no branches on it inside the eight evaluations of a thread
+        hipLaunchKernelGGL((k_acquire_argmax<false, 0>), dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, vsrc,
+                           (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi, inc_parts, n_parts,
+                           ctx->inc_dev, c01);
+    else if (acq == GPBO_ACQ_UCB)
+        hipLaunchKernelGGL((k_acquire_argmax<false, 1>), dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, vsrc,
+                           (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi, inc_parts, n_parts,
+                           ctx->inc_dev, c01);
     else
-        hipLaunchKernelGGL(k_acquire_argmax<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, vsrc,
+        hipLaunchKernelGGL((k_acquire_argmax<false, 2>), dim3(blocks), dim3(256), 0, ctx->stream, (const double*)ctx->mu, vsrc,
                            (long)ctx->m, acq, kappa, (const double*)ctx->inc_dev, ctx->acq, ctx->acq_pv, ctx->acq_pi, inc_parts, n_parts,
                            ctx->inc_dev, c01);
     // (the last argmax stage, over the `blocks` per-workgroup results, runs inside the end-of-step launch: step_fetch)

@@ -152,28 +152,62 @@ __global__ __launch_bounds__(256) void k_first_ge_stage(const double* __restrict
 }
 
 // erfc(z) for z >= 0 as  t exp(-z^2) G(2t - 1),  t = 2 / (2 + z):  G(u) = exp(z^2) erfc(z) / t is smooth on [-1, 1]
-// (1 / (2 sqrt(pi)) at u = -1, i.e. z = inf; 1 at u = 1, i.e. z = 0) and its Chebyshev series converges like 0.2^k.  The 28
-// coefficients below were obtained by projecting G onto T_0 .. T_95 in 60-digit arithmetic; truncated here the series is
-// within 9e-18 (relative) of G over the whole range.  One formula for every z: no range branches for a wave to diverge
-// on, and the exponential is the one the normal density needs as well.
+// (1 / (2 sqrt(pi)) at u = -1, i.e. z = inf; 1 at u = 1, i.e. z = 0) and its Chebyshev series converges like 0.2^k.  G was
+// projected onto T_0 .. T_95 in 60-digit arithmetic, truncated after T_27 (within 9e-18, relative, of G over the whole
+// range) and re-expanded in powers of u: the 28 coefficients below (scripts/erfcx_chebyshev.py).  They fall off like 0.4^k
+// and their absolute values sum to 1.03 where G(1) = 1, so Horner's rule -- one FMA per term, half the arithmetic of
+// Clenshaw's recurrence on the Chebyshev form -- loses nothing: 2.0e-16 from G in binary64 against 3.8e-16.  One formula for
+// every z: no range branches for a wave to diverge on, and the exponential is the one the normal density needs as well.
+// The table sits in constant memory, not in the instruction stream: a wave reads it once into scalar registers and every
+// term is one v_fma_f64 with a scalar addend (as literals each coefficient costs two more vector moves per use).
+__constant__ double ERFCX_POW[28] = {
+    0.5107913526210114891,      0.34358034220690527304,      0.13973604627802689131,      0.018221115753442496732,
+    -0.010755330944716363879,   -0.0032395925339865131725,   0.0015453060290576436895,    0.0004186480332964868087,
+    -0.00033153674761946044252, -0.000017185737594548939107, 0.000072235350614385433482,  -0.000017074336530735700106,
+    -0.000010848057268891095768, 8.0600404910281462479e-6,   -5.6281669351929246327e-7,   -1.8208078384029821516e-6,
+    1.0009185862654101138e-6,   -3.0587196456747097464e-9,   -2.8554818238341171664e-7,   1.6491163111184632914e-7,
+    -1.6982724012935666188e-9,  -5.7601466971756245011e-8,   2.9041985444209085665e-8,    6.3538646695051392166e-9,
+    -9.744756625932257797e-9,   1.22845363501865661e-9,      1.2051665995883636701e-9,    -3.3888695546308688491e-10};
 __device__ __forceinline__ double erfcx_over_t(double u) {
-    constexpr double c[28] = {
-        0.57703373861646968862,     0.35543692127049848731,     0.06509515882878652455,     0.0036711423958366391659,
-        -0.0011128447433526324969,  -0.00016075829915378079758, 0.000032780315741731370605, 5.4424416455050160333e-6,
-        -1.5154665553171481622e-6,  -1.4297608181169864917e-7,  8.234608827419493433e-8,    -1.2962846852306562536e-9,
-        -4.1547216310151983042e-9,  6.3470582783628111814e-10,  1.4320822712256223707e-10,  -6.1603901052045855418e-11,
-        2.0612138554721696306e-12,  3.571493148847704445e-12,   -8.5864228432517964757e-13, -6.145600213790630554e-14,
-        7.4187257485966170573e-14,  -1.2895042755032325615e-14, -2.3587263857106323568e-15, 1.5729349381685911397e-15,
-        -2.2782966239546465174e-16, -6.3123304507564298101e-17, 3.5916763531814922992e-17,  -5.0498091498477292793e-18};
-    const double u2 = 2.0 * u;
-    double b1 = 0.0, b2 = 0.0;
+    double p = ERFCX_POW[27];
 #pragma unroll
-    for (int k = 27; k >= 1; --k) {          // Clenshaw
-        const double b0 = fma(u2, b1, c[k] - b2);
-        b2 = b1;
-        b1 = b0;
-    }
-    return fma(u, b1, c[0] - b2);
+    for (int k = 26; k >= 0; --k) p = fma(p, u, ERFCX_POW[k]);
+    return p;
+}
+
+// a * b + c with the constant c held in a scalar register pair.  For a 64-bit literal addend the compiler otherwise builds
+// the constant in a vector register pair (two vector moves) in front of every v_fmac_f64: three vector instructions per
+// Horner step instead of one.
+__device__ __forceinline__ double fma_sc(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+// exp(x) for x <= 0 (or NaN), the algorithm and coefficients of the device library's exp (range reduction by ln 2 in two
+// parts, degree-11 polynomial, ldexp; results identical to exp(x) bit for bit: scripts/exp_neg_probe.hip) with the
+// polynomial's constants in scalar registers (fma_sc): 20 vector instructions fewer per value.
+__device__ __forceinline__ double exp_neg(double x) {
+    constexpr double LOG2E = __builtin_bit_cast(double, 0x3ff71547652b82feULL);
+    constexpr double LN2_HI = __builtin_bit_cast(double, 0x3fe62e42fefa39efULL);
+    constexpr double LN2_LO = __builtin_bit_cast(double, 0x3c7abc9e3b39803fULL);
+    const double n = __builtin_rint(x * LOG2E);
+    double r = fma(-LN2_HI, n, x);
+    r = fma(-LN2_LO, n, r);
+    double p = fma_sc(r, __builtin_bit_cast(double, 0x3e5ade156a5dcb37ULL), __builtin_bit_cast(double, 0x3e928af3fca7ab0cULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3ec71dee623fde64ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3efa01997c89e6b0ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f2a01a014761f6eULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f56c16c1852b7b0ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f81111111122322ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fa55555555502a1ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fc5555555555511ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fe000000000000bULL));
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    double z = ldexp(p, (int)n);
+    if (x < -1075.0) z = 0.0;
+    return z;
 }
 
 // One candidate's acquisition value: EI (BayesOpt_v4.ipynb:188-197: imp Phi(Z) + sigma phi(Z), ei[sigma == 0] = 0), UCB
@@ -189,7 +223,7 @@ __device__ __forceinline__ double acq_value(double mj, double vj, double inc, in
     const double z = fabs(Z) * 0.70710678118654752440;
     const double t = 2.0 / (2.0 + z);
     const double ZZ = Z * Z;
-    const double E = exp(-ZZ / 2.0);             // the density's exponential, formed as the reference forms it
+    const double E = exp_neg(-ZZ / 2.0);         // the density's exponential, formed as the reference forms it
     // for the distribution function the rounding of Z * Z (worth Z^2 ulp in the far tail) is put back: exp(-(ZZ + e) / 2) = E (1 - e / 2)
     const double Ec = (ZZ < INFINITY) ? fma(E, -0.5 * fma(Z, Z, -ZZ), E) : E;
     const double half_erfc = 0.5 * t * Ec * erfcx_over_t(2.0 * t - 1.0);
@@ -229,7 +263,7 @@ __device__ __forceinline__ double block_max_of_parts(const double* __restrict__ 
     return r;
 }
 
-template <bool STORE>
+template <bool STORE, int ACQ = -1>
 __global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict__ mu, const double* __restrict__ var, long m, int acq,
                                                         double kappa, const double* __restrict__ inc_ptr, double* __restrict__ out,
                                                         double* __restrict__ part_v, long* __restrict__ part_i,
@@ -254,16 +288,25 @@ __global__ __launch_bounds__(256) void k_acquire_argmax(const double* __restrict
     }
     double bv = -INFINITY;
     long bi = INT64_MAX;
+    // all of the thread's candidates are requested before the first is evaluated (inside the bounds check of each one the
+    // loads would wait in turn: eight memory round trips per thread instead of one)
+    double mj[ACQ_PER], vj[ACQ_PER];
+#pragma unroll
+    for (int u = 0; u < ACQ_PER; ++u) {
+        const long j = base + u * 256 + tid;
+        mj[u] = (j < m) ? mu[j] : 0.0;
+        vj[u] = (j < m) ? var[j] : 0.0;
+    }
 #pragma unroll
     for (int u = 0; u < ACQ_PER; ++u) {
         const long j = base + u * 256 + tid;
         if (j < m) {
-            double vj = var[j];
+            double v = vj[u];
             if (c01) {
-                vj = c01[0] - c01[1] * vj;
-                if (vj < 1e-60) vj = 0.0;
+                v = c01[0] - c01[1] * v;
+                if (v < 1e-60) v = 0.0;
             }
-            const double r = acq_value(mu[j], vj, inc, acq, kappa);
+            const double r = acq_value(mj[u], v, inc, ACQ >= 0 ? ACQ : acq, kappa);       // (ACQ >= 0: the acquisition is fixed at compile time)
             if (STORE) out[j] = r;
             if (better(r, j, bv, bi)) {
                 bv = r;

@@ -13,22 +13,21 @@ from oracle import gp_oracle as o
 
 def table():
     src = open(os.path.join(ROOT, 'bayesian_optimization_amd', 'csrc', 'k_acquisition.hpp')).read()
-    blk = src[src.index('constexpr double c[28] = {'):]
+    blk = src[src.index('__constant__ double ERFCX_POW[28] = {'):]
     c = np.array([float(x) for x in re.sub(r'\s+', ' ', blk[blk.index('{') + 1:blk.index('}')]).split(',')])
     assert c.shape == (28,)
     return c
 
 
 def phi_parts(Z, c):
-    """(Phi, density exponential) with the device's operations (Clenshaw, one exponential, the Z * Z rounding put back)."""
+    """(Phi, density exponential) with the device's operations (Horner's rule on the power-basis table, one exponential, the
+    Z * Z rounding put back); NumPy has no fused multiply-add, so every Horner step rounds twice where the device rounds once."""
     z = np.abs(Z) * 0.70710678118654752440
     t = 2.0 / (2.0 + z)
     u = 2.0 * t - 1.0
-    b1 = np.zeros_like(u)
-    b2 = np.zeros_like(u)
-    for k in range(27, 0, -1):
-        b1, b2 = 2.0 * u * b1 + (c[k] - b2), b1
-    g = u * b1 + (c[0] - b2)
+    g = np.full_like(u, c[27])
+    for k in range(26, -1, -1):
+        g = g * u + c[k]
     ZZ = Z * Z
     E = np.exp(-ZZ / 2.0)
     with np.errstate(invalid='ignore'):
