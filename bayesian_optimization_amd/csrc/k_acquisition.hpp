@@ -175,41 +175,6 @@ __device__ __forceinline__ double erfcx_over_t(double u) {
     return p;
 }
 
-// a * b + c with the constant c held in a scalar register pair.  For a 64-bit literal addend the compiler otherwise builds
-// the constant in a vector register pair (two vector moves) in front of every v_fmac_f64: three vector instructions per
-// Horner step instead of one.
-__device__ __forceinline__ double fma_sc(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
-}
-
-// exp(x) for x <= 0 (or NaN), the algorithm and coefficients of the device library's exp (range reduction by ln 2 in two
-// parts, degree-11 polynomial, ldexp; results identical to exp(x) bit for bit: scripts/exp_neg_probe.hip) with the
-// polynomial's constants in scalar registers (fma_sc): 20 vector instructions fewer per value.
-__device__ __forceinline__ double exp_neg(double x) {
-    constexpr double LOG2E = __builtin_bit_cast(double, 0x3ff71547652b82feULL);
-    constexpr double LN2_HI = __builtin_bit_cast(double, 0x3fe62e42fefa39efULL);
-    constexpr double LN2_LO = __builtin_bit_cast(double, 0x3c7abc9e3b39803fULL);
-    const double n = __builtin_rint(x * LOG2E);
-    double r = fma(-LN2_HI, n, x);
-    r = fma(-LN2_LO, n, r);
-    double p = fma_sc(r, __builtin_bit_cast(double, 0x3e5ade156a5dcb37ULL), __builtin_bit_cast(double, 0x3e928af3fca7ab0cULL));
-    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3ec71dee623fde64ULL));
-    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3efa01997c89e6b0ULL));
-    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f2a01a014761f6eULL));
-    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f56c16c1852b7b0ULL));
-    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f81111111122322ULL));
-    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fa55555555502a1ULL));
-    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fc5555555555511ULL));
-    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fe000000000000bULL));
-    p = fma(r, p, 1.0);
-    p = fma(r, p, 1.0);
-    double z = ldexp(p, (int)n);
-    if (x < -1075.0) z = 0.0;
-    return z;
-}
-
 // One candidate's acquisition value: EI (BayesOpt_v4.ipynb:188-197: imp Phi(Z) + sigma phi(Z), ei[sigma == 0] = 0), UCB
 // (GP/BayesOpt_v1.m:248-251) or PI (Gaussian_Process_Regression.ipynb:265-268).  Phi(Z) = erfc(-Z / sqrt 2) / 2 for Z < 0 and
 // 1 - erfc(Z / sqrt 2) / 2 otherwise, phi(Z) = exp(-Z^2 / 2) / sqrt(2 pi): one exponential serves both.  Every kernel that

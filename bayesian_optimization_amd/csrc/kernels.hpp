@@ -95,18 +95,54 @@ __device__ __forceinline__ void band_decode(int t, int T, int& i, int& j) {
     j = R * b + rj;
 }
 
+// a * b + c with the constant c held in a scalar register pair.  For a 64-bit literal addend the compiler otherwise builds
+// the constant in a vector register pair (two vector moves) in front of every v_fmac_f64: three vector instructions per
+// Horner step instead of one.
+__device__ __forceinline__ double fma_sc(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+// exp(x) for x <= 0 (or NaN).  Every exponential on this path is of that kind: a covariance, the normal density.  The
+// algorithm and the coefficients are those of the device library's exp (range reduction by ln 2 in two parts, degree-11
+// polynomial, ldexp), the results identical to exp(x) bit for bit (scripts/exp_neg_probe.hip: 2^25 arguments and the special
+// values), but the polynomial's constants sit in scalar registers (fma_sc): 20 vector instructions fewer per value.
+__device__ __forceinline__ double exp_neg(double x) {
+    constexpr double LOG2E = __builtin_bit_cast(double, 0x3ff71547652b82feULL);
+    constexpr double LN2_HI = __builtin_bit_cast(double, 0x3fe62e42fefa39efULL);
+    constexpr double LN2_LO = __builtin_bit_cast(double, 0x3c7abc9e3b39803fULL);
+    const double n = __builtin_rint(x * LOG2E);
+    double r = fma(-LN2_HI, n, x);
+    r = fma(-LN2_LO, n, r);
+    double p = fma_sc(r, __builtin_bit_cast(double, 0x3e5ade156a5dcb37ULL), __builtin_bit_cast(double, 0x3e928af3fca7ab0cULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3ec71dee623fde64ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3efa01997c89e6b0ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f2a01a014761f6eULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f56c16c1852b7b0ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3f81111111122322ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fa55555555502a1ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fc5555555555511ULL));
+    p = fma_sc(r, p, __builtin_bit_cast(double, 0x3fe000000000000bULL));
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    double z = ldexp(p, (int)n);
+    if (x < -1075.0) z = 0.0;
+    return z;
+}
+
 __device__ __forceinline__ double kern_eval(double D, int kernel) {
-    if (kernel == 0) return exp(-0.5 * D);
+    if (kernel == 0) return exp_neg(-0.5 * D);
     const double r = sqrt(D);
     const double s5r = 2.23606797749978969641 * r;
-    return (1.0 + s5r + (5.0 / 3.0) * D) * exp(-s5r);
+    return (1.0 + s5r + (5.0 / 3.0) * D) * exp_neg(-s5r);
 }
 
 // -2 dk/d(D) as a function of the scaled squared distance D: the factor F in dK/dtheta_t = F q_t / theta_t.
 __device__ __forceinline__ double kern_dfac(double D, int kernel) {
-    if (kernel == 0) return exp(-0.5 * D);
+    if (kernel == 0) return exp_neg(-0.5 * D);
     const double s5r = 2.23606797749978969641 * sqrt(D);
-    return (5.0 / 3.0) * (1.0 + s5r) * exp(-s5r);
+    return (5.0 / 3.0) * (1.0 + s5r) * exp_neg(-s5r);
 }
 
 }  // namespace gpbo

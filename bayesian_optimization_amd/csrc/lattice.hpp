@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_lattice_points(LatticeDesc L, const dou
 __device__ __forceinline__ double lattice_factor(const LatticeDesc& L, const double* __restrict__ axes, const double* __restrict__ params,
                                                  int t, int g, double xts) {
     const double df = axes[L.off[t] + g] * params[P_INVTHETA + t] - xts;
-    return exp(-0.5 * df * df);
+    return exp_neg(-0.5 * df * df);
 }
 
 // Row i of the per-axis factor table of the prefix axes, E[(t * smax + g) * kcap + i], and of B (k-major: B[i * ldb + q],

@@ -1,5 +1,5 @@
-// exp_neg (csrc/k_acquisition.hpp) against the device library's exp, bit for bit, over 2^25 arguments in [-1100, 0] (the range
-// the acquisition uses: -Z^2 / 2), every exponent boundary region included, and the special values.
+// exp_neg (csrc/kernels.hpp) against the device library's exp, bit for bit, over 2^25 arguments in [-1100, 0] (the range
+// the covariance functions and the normal density use), every exponent boundary region included, and the special values.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/exp_neg_probe scripts/exp_neg_probe.hip && scripts/exp_neg_probe
 #include <hip/hip_runtime.h>
 #include <cmath>
