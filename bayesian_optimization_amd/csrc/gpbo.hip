@@ -74,6 +74,12 @@ struct gpbo_ctx {
     double *lat_axes = nullptr, *latA = nullptr, *latB = nullptr, *latE = nullptr, *lat_bmax = nullptr;
     int64_t lat_axes_cap = 0, lat_kcap = 0, lat_ppad = 0, lat_qpad = 0, lat_smax = 0, lat_a_cap = 0, lat_b_cap = 0, lat_e_cap = 0,
             lat_bmax_cap = 0, sres_cap = 0;
+    // acquisition inside the lattice route's update launch (append_acquire): per-tile results, the incumbent slot, and whether
+    // the device knows where the largest mean of the current posterior sits (lattice.hpp: SpecArgs)
+    double *lat_tile_v = nullptr, *spec_dev = nullptr;
+    long *lat_tile_i = nullptr, *lat_mu_i = nullptr;
+    int64_t lat_tile_cap = 0;
+    bool mu_argmax_valid = false;
     long sweep_parts = 0;       // per-workgroup max(mu) partials the last append left in its first-stage buffer
     double* sweep_part_buf = nullptr;
 
@@ -600,6 +606,13 @@ int lattice_ensure(gpbo_ctx* ctx) {
         CHK(dev_alloc(ctx, &ctx->lat_bmax, (size_t)tiles));
         ctx->lat_bmax_cap = tiles;
     }
+    if (tiles > ctx->lat_tile_cap) {
+        CHK(dev_alloc(ctx, &ctx->lat_tile_v, (size_t)tiles));
+        CHK(dev_alloc(ctx, &ctx->lat_tile_i, (size_t)tiles));
+        CHK(dev_alloc(ctx, &ctx->lat_mu_i, (size_t)tiles));
+        ctx->lat_tile_cap = tiles;
+    }
+    if (!ctx->spec_dev) CHK(dev_alloc(ctx, &ctx->spec_dev, 8));
     HIPCHK(hipMemsetAsync(ctx->latA, 0, (size_t)a_need * sizeof(double), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->latB, 0, (size_t)b_need * sizeof(double), ctx->stream));
     ctx->lat_kcap = kcap;
@@ -727,6 +740,7 @@ int posterior_impl(gpbo_ctx* ctx, double* mu_max_out) {
     ctx->have_acq = false;
     ctx->inc_valid = keep_inc;
     ctx->inc_lattice = lat;
+    ctx->mu_argmax_valid = false;
     ctx->var_stale = false;
     if (mu_max_out) *mu_max_out = mu_max;
     return GPBO_OK;
@@ -765,7 +779,28 @@ int append_check(gpbo_ctx* ctx, const double* x_new) {
 
 // factor update (O(n^2)) + the HBM-streaming sweep over the resident V with max(mu) folded into its epilogue.
 // Leaves max(mu) in inc_dev[1].  Call timing_begin first.
-int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new, bool defer_last_max = false) {
+// What the acquisition that follows an append wants, for the routes that can carry it inside the update launch.
+struct AcqRequest {
+    int acq, mode;
+    double kappa, incumbent;
+    bool carried = false;        // out: the update launch evaluated the acquisition and the step's last launch was enqueued
+};
+
+// GPBO_LATTICE_SPEC=0: the lattice route keeps the acquisition in a launch of its own.
+bool lattice_spec_enabled() {
+    static const bool on = !(getenv("GPBO_LATTICE_SPEC") && atoi(getenv("GPBO_LATTICE_SPEC")) == 0);
+    return on;
+}
+
+template <int ACQ>
+void launch_update_acq(gpbo_ctx* ctx, long tiles, int tiles_q, int kpad, double kappa) {
+    TileBest tb{ctx->lat_tile_v, ctx->lat_tile_i, ctx->lat_bmax, ctx->lat_mu_i};
+    hipLaunchKernelGGL(k_lattice_gemm_update_acq<ACQ>, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, ctx->stream, (const double*)ctx->latA,
+                       (long)ctx->lat_kcap, (const double*)ctx->latB, (long)ctx->lat_qpad, kpad, ctx->lat.P, ctx->lat.Q, tiles_q,
+                       (const double*)ctx->scal, (const double*)ctx->params, (const double*)ctx->spec_dev, kappa, ctx->sres, ctx->mu, tb);
+}
+
+int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new, bool defer_last_max = false, AcqRequest* rq = nullptr) {
     const int n = (int)ctx->n;
     const long ld = ctx->n_pad;
     PointArg pa;
@@ -828,13 +863,45 @@ int append_enqueue(gpbo_ctx* ctx, const double* x_new, double y_new, bool defer_
                                (const double*)ctx->lat_axes, (const double*)ctx->params, (const double*)ctx->Xts, (long)ctx->n_pad, n,
                                ctx->latE, (int)ctx->lat_kcap, (int)ctx->lat_smax, ctx->latB, (long)ctx->lat_qpad);
         }
-        hipLaunchKernelGGL(k_lattice_A, dim3((unsigned)((ctx->lat.P * kpad + 255) / 256)), dim3(256), 0, ctx->stream, ctx->lat,
+        // with an acquisition to follow, the update launch evaluates it as well (lattice.hpp: SpecArgs); the incumbent it
+        // needs is formed by one more workgroup of the launch that builds A
+        const bool carry = rq && lattice_spec_enabled();
+        SpecArgs sp{};
+        if (carry) {
+            sp.spec = ctx->spec_dev;
+            sp.mode = rq->acq == GPBO_ACQ_UCB ? 2 : (rq->mode == GPBO_INCUMBENT_MAX_MU ? 0 : (rq->mode == GPBO_INCUMBENT_MAX_Y ? 1 : 2));
+            sp.have = ctx->mu_argmax_valid ? 1 : 0;
+            sp.given = rq->acq == GPBO_ACQ_UCB ? 0.0 : rq->incumbent;
+            sp.B = ctx->latB;
+            sp.ldb = (long)ctx->lat_qpad;
+            sp.mu = ctx->mu;
+            sp.scal = ctx->scal;
+            sp.params = ctx->params;
+            sp.kpad = kpad;
+        }
+        hipLaunchKernelGGL(k_lattice_A, dim3((unsigned)((ctx->lat.P * kpad + 255) / 256) + (carry ? 1u : 0u)), dim3(256), 0, ctx->stream, ctx->lat,
                            (const double*)ctx->latE, (int)ctx->lat_kcap, (int)ctx->lat_smax, (const double*)(ctx->bufW + (long)n * ld), n,
-                           ctx->latA, (long)ctx->lat_kcap, kpad);
+                           ctx->latA, (long)ctx->lat_kcap, kpad, sp);
+        if (carry) {
+            switch (rq->acq) {
+                case GPBO_ACQ_EI: launch_update_acq<0>(ctx, tiles, tiles_q, kpad, rq->kappa); break;
+                case GPBO_ACQ_UCB: launch_update_acq<1>(ctx, tiles, tiles_q, kpad, rq->kappa); break;
+                default: launch_update_acq<2>(ctx, tiles, tiles_q, kpad, rq->kappa); break;
+            }
+            TileBest tb{ctx->lat_tile_v, ctx->lat_tile_i, ctx->lat_bmax, ctx->lat_mu_i};
+            hipLaunchKernelGGL(k_spec_finish, dim3(1), dim3(1024), 0, ctx->stream, tb, tiles, (const double*)ctx->params, (const int*)ctx->info_dev,
+                               ctx->spec_dev, sp.mode == 0 ? 1 : 0, sp.have, ctx->inc_dev, ctx->res_dev);
+            ctx->var_stale = true;
+            ctx->mu_argmax_valid = true;      // (k_spec_finish leaves the index of the largest mean behind)
+            rq->carried = true;
+            HIPCHK(hipGetLastError());
+            return GPBO_OK;
+        }
         hipLaunchKernelGGL(k_lattice_gemm_update, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, ctx->stream, (const double*)ctx->latA,
                            (long)ctx->lat_kcap, (const double*)ctx->latB, (long)ctx->lat_qpad, kpad, ctx->lat.P, ctx->lat.Q, tiles_q,
                            (const double*)ctx->scal, ctx->sres, ctx->mu, ctx->lat_bmax);
         ctx->var_stale = true;
+        ctx->mu_argmax_valid = false;
         ctx->sweep_parts = tiles;
         ctx->sweep_part_buf = ctx->lat_bmax;
     } else {
@@ -997,11 +1064,35 @@ int append_acquire_impl(gpbo_ctx* ctx, const double* x_new, double y_new, int ac
     if (acq < 0 || acq > 2) BADARG("append_acquire: unknown acquisition");
     if (mode < 0 || mode > 2) BADARG("append_acquire: unknown incumbent mode");
     timing_begin(ctx);
-    CHK(append_enqueue(ctx, x_new, y_new, mode == GPBO_INCUMBENT_MAX_MU));
-    CHK(acquire_enqueue(ctx, acq, kappa, mode, incumbent, false, true));
+    AcqRequest rq{acq, mode, kappa, incumbent};
+    CHK(append_enqueue(ctx, x_new, y_new, mode == GPBO_INCUMBENT_MAX_MU, ctx->inc_lattice ? &rq : nullptr));
     StepResult r{};
-    CHK(step_fetch(ctx, &r, true, true));
+    bool settled = false, spec_hit = false;
+    if (rq.carried) {
+        // the update launch evaluated the acquisition and the step's last launch has written the result block; what is left
+        // to find out is whether the incumbent it worked with was the right one
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        settled = spec_hit = ctx->res_host[12] != 0.0;
+        if (settled) {
+            memcpy(r.par, ctx->res_host, sizeof(r.par));
+            r.info = (int)ctx->res_host[8];
+            r.mu_max = ctx->res_host[9];
+            r.best = ctx->res_host[10];
+            memcpy(&r.best_i, ctx->res_host + 11, sizeof(long));
+        } else if ((int)ctx->res_host[8] != 0) {
+            memcpy(r.par, ctx->res_host, sizeof(r.par));       // the append itself failed: no acquisition to repeat
+            r.info = (int)ctx->res_host[8];
+            r.mu_max = ctx->res_host[9];
+            settled = true;
+        }
+    }
+    if (!settled) {
+        // (after a carried update: max(mu) is in the incumbent slots, k_spec_finish put it there)
+        CHK(acquire_enqueue(ctx, acq, kappa, mode, incumbent, false, !rq.carried));
+        CHK(step_fetch(ctx, &r, true, true));
+    }
     CHK(append_finish(ctx, r, mu_max_out));
+    if (spec_hit) ctx->tm.append_route = 2.0;      // lattice route, acquisition carried by the update launch and kept
     if (r.best_i == INT64_MAX) r.best_i = 0;
     if (argmax_out) *argmax_out = r.best_i;
     if (best_out) *best_out = r.best;
@@ -1099,7 +1190,7 @@ void gpbo_destroy(gpbo_ctx* ctx) {
     void* ps[] = {ctx->params, ctx->info_dev, ctx->red_v, ctx->red_i, ctx->red_v2, ctx->red_i2, ctx->inc_dev,
                   ctx->Xs,     ctx->mu,       ctx->var,   ctx->acq,   ctx->Bmat,   ctx->partial, ctx->mupart,
                   ctx->scal,   ctx->xnew_dev, ctx->Vres,  ctx->sres,     ctx->acq_pv,  ctx->acq_pi, ctx->bmax, ctx->Zmat,
-                  ctx->lat_axes, ctx->latA,   ctx->latB,  ctx->latE,     ctx->lat_bmax};
+                  ctx->lat_axes, ctx->latA,   ctx->latB,  ctx->latE,     ctx->lat_bmax, ctx->lat_tile_v, ctx->lat_tile_i, ctx->lat_mu_i, ctx->spec_dev};
     for (void* p : ps)
         if (p) hipFree(p);
     if (ctx->res_host) hipHostFree(ctx->res_host);
@@ -1892,6 +1983,7 @@ int gpbo_set_posterior(gpbo_ctx* ctx, const double* mu, const double* var, int64
     HIPCHK(hipMemcpyAsync(ctx->mu, mu, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->var, var, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
     ctx->var_stale = false;
+    ctx->mu_argmax_valid = false;
     CHK(reduce_max(ctx, ctx->mu, m, ctx->inc_dev + 1));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_posterior = true;

@@ -351,7 +351,7 @@ def cfg4_block(a, gp, world, rank, backend, iters, warmup, lattice=False):
                                    'factors, no resident V' % (side ** ((d + 1) // 2), side ** (d // 2)) if lattice else
                                    '; candidates given as points: per-append update streams the resident V')),
                    'n_final': gp.n, 'best_y': float(gp.y_max), 'picked_head': [int(j) for j in picked[:16]]},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_lattice_gemm_update (+ factor build)' if lattice else 'k_append_sweep', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'roofline': {'bound': 'hbm', 'kernel': 'k_lattice_gemm_update_acq (update and acquisition of all candidates in one launch; + factor build)' if lattice else 'k_append_sweep', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': sweep_ms / max(timed, 1),
                      'bytes_per_launch_avg': bytes_alg / max(timed, 1), 'launches_timed': timed}}
 

@@ -71,7 +71,8 @@ typedef struct gpbo_timings {
     double trmm_flops;     /* algorithmic flops of the trmm launches: n_pad-free count n^2 per candidate */
     double append_total_ms;  /* last gpbo_append: factor update + sweep + max(mu) */
     double append_sweep_ms;  /* the update of the candidates' posterior inside the last gpbo_append */
-    double append_route;     /* how that update ran: 0 = pass over the resident V, 1 = product of per-axis factors (lattice) */
+    double append_route;     /* how that update ran: 0 = pass over the resident V, 1 = product of per-axis factors (lattice),
+                                2 = the same with the acquisition of gpbo_append_acquire evaluated inside the update launch */
 } gpbo_timings;
 
 /* Device-side description of a fitted model, for broadcasting it to other ranks

@@ -76,7 +76,7 @@ def test_lattice_loop_equals_the_streaming_loop_a_refit_and_the_oracle(d):
             Xa.append(grid[picks[-1]][None, :])
             ya.append(np.array([objective(grid[picks[-1]])]))
             picks.append(j)
-            assert gp.timings()['append_route'] == (1.0 if use_lattice and d > 1 else 0.0)      # one axis: nothing to factorise
+            assert (gp.timings()['append_route'] >= 1.0) == (use_lattice and d > 1)      # one axis: nothing to factorise (2.0: the update launch carried the acquisition)
         mu, var = gp.read()
         assert mu_max == mu.max()
         runs.append(dict(picks=picks, mu=mu, var=var, theta1=gp.theta1, nll=gp.nll, X=np.vstack(Xa), y=np.concatenate(ya)))
@@ -145,7 +145,7 @@ def test_lattice_loop_over_several_contexts_is_bit_identical_to_one(contexts):
             seq.append((j, v, mu_max))
         out.append((seq, gp.read(), gp.theta1, gp.nll))
         if isinstance(gp, MultiGP):
-            assert all(g.timings()['append_route'] == 1.0 for g in gp.contexts)
+            assert all(g.timings()['append_route'] >= 1.0 for g in gp.contexts)
             assert [hi - lo for lo, hi in gp.blocks()] == [len(b) * (len(grid) // 6) for b in np.array_split(np.arange(6), contexts)]
         gp.close()
     assert out[0][0] == out[1][0]
@@ -207,7 +207,7 @@ def test_refit_with_other_length_scales_rebuilds_the_factor_tables():
         for _ in range(reserve):
             Xa = np.vstack([Xa, grid[j][None, :]])
             mu_max, j, _ = gp.append_acquire(grid[j], float(objective(grid[j])), bo.ACQ_EI, 0.01, bo.INCUMBENT_MAX_MU)
-            assert gp.timings()['append_route'] == 1.0
+            assert gp.timings()['append_route'] >= 1.0
         mu, var = gp.read()
         mu_o, var_o, _ = o.gprfcn_diag(grid, Xa, objective(Xa), theta, sY, variant=bo.VARIANT_SINGLE)
         assert relmax(mu, mu_o) <= TOL_MU and relmax(var, var_o) <= TOL_VAR and mu_max == mu.max()
@@ -223,5 +223,18 @@ def test_one_launch_factor_update_equals_the_separate_launches():
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'check_fused_append.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'differing 0' in r.stdout
+
+
+def test_acquisition_carried_by_the_update_launch_equals_the_separate_pass():
+    """append_acquire on the lattice route evaluates the acquisition inside the update launch; with max(mu) as incumbent it
+    speculates on where that maximum sits (the candidate that held it so far) and falls back to the separate pass when it
+    moved.  GPBO_LATTICE_SPEC=0 keeps the separate pass.  The same loops in two child processes (EI with each incumbent
+    mode, UCB, PI; plain appends in between; ragged lattices): picks, acquisition maxima, max(mu), theta1, -log L, mean and
+    variance bit for bit, both outcomes of the speculation exercised, known incumbents always kept."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'check_lattice_spec.py')], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'differing 0' in r.stdout
