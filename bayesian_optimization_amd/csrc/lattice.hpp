@@ -237,7 +237,7 @@ struct TileBest {
     long* mu_i;         // ... and its candidate index
 };
 template <int ACQ>
-__global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update_acq(const double* __restrict__ A, long lda, const double* __restrict__ B,
+__global__ __launch_bounds__(GEMM_THREADS, 3) void k_lattice_gemm_update_acq(const double* __restrict__ A, long lda, const double* __restrict__ B,
                                                                                long ldb, int kpad, long P, long Q, int tiles_q,
                                                                                const double* __restrict__ scal, const double* __restrict__ params,
                                                                                const double* __restrict__ inc_ptr, double kappa,
@@ -264,8 +264,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update_acq(con
                 s_old[ta][r][tb] = in ? sres[j] : 0.0;
             }
         }
-    gemm_tile_64x64<false>(A + (long)ib * QUARTER_M * lda, lda, B + (long)jb * 64, ldb, 0, kpad, acc, lds);
-    // the old means all at once (the stores of the loop below go to the same array: inside it each load would wait behind them)
+    // ... and the old means with them: three workgroups per CU (170 registers) hold both beside the accumulators, and with the
+    // acquisition's arithmetic in the epilogue that beats four per CU loading the means after the product (0.2388 against
+    // 0.2415-0.2436 ms per iteration; the update alone prefers four, see above).  Inside the epilogue loop each load would
+    // wait behind the stores to the same array.
     double m_old[2][4][2];
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void k_lattice_gemm_update_acq(con
                 m_old[ta][r][tb] = in ? mu[row * Q + col] : 0.0;
             }
         }
+    gemm_tile_64x64<false>(A + (long)ib * QUARTER_M * lda, lda, B + (long)jb * 64, ldb, 0, kpad, acc, lds);
     const double znew = scal[A_ZNEW], c0 = params[P_C0], c1 = params[P_C1], inc = *inc_ptr;
     double bv = -INFINITY, mv = -INFINITY;
     long bi = INT64_MAX, mi = INT64_MAX;
