@@ -144,11 +144,31 @@ for seq in range(seqs):
                     except REFUSE:
                         pass
                     continue
-                gp.append(x_new, y_new)
+                fusedcall = rng.random() < 0.5          # append + acquisition in one call (the routes may carry it in the update launch)
+                if fusedcall:
+                    acqk, modek = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+                    mm1, jj, bb = gp.append_acquire(x_new, y_new, acqk, 0.05, modek, 0.1)
+                else:
+                    gp.append(x_new, y_new)
                 counts['append carried out'] = counts.get('append carried out', 0) + 1
                 S['X'] = np.vstack([S['X'], x_new[None, :]]); S['y'] = np.append(S['y'], y_new); S['left'] -= 1
                 mu_o, var_o = oracle_posterior(S)
                 mu, var = gp.read()
+                if fusedcall:
+                    # against the two-call form on the device's own posterior: same maximum, same first index, same max(mu)
+                    inc = {0: float(mu.max()), 1: float(S['y'].max()), 2: 0.1}[modek]
+                    sg = np.sqrt(var)
+                    with np.errstate(all='ignore'):
+                        if acqk == 1:
+                            vals = mu + 0.05 * sg
+                        else:
+                            vals = o.expected_improvement(mu.copy(), var, 0.05, incumbent=inc) if acqk == 0 else o.probability_of_improvement(mu, inc, sg)
+                    if mm1 != mu.max():
+                        report(seq, step, op, 'append_acquire max(mu) %r vs %r' % (mm1, float(mu.max())))
+                    if vals is not None and np.all(np.isfinite(vals)):
+                        top = float(vals.max())
+                        if abs(bb - top) > 1e-9 * max(abs(top), 1e-300) + 1e-300 or vals[jj] < top - 1e-9 * max(abs(top), 1e-300):
+                            report(seq, step, op, 'append_acquire acq %d mode %d: best %r at %d, own maximum %r at %d' % (acqk, modek, bb, jj, top, int(np.argmax(vals))))
                 if rel(mu, mu_o) > 1e-8 or float(np.max(np.abs(var - var_o))) > 1e-8 * max(float(np.max(np.abs(var_o))), 1e-300) or gp.n != len(S['y']):
                     report(seq, step, op, 'mu %.2e var %.2e n %d' % (rel(mu, mu_o), float(np.max(np.abs(var - var_o))), gp.n))
                 S.update(mu=mu_o, var=var_o, acq=False)
