@@ -106,7 +106,7 @@ __device__ __forceinline__ double fma_sc(double a, double b, double c) {
 
 // exp(x) for x <= 0 (or NaN).  Every exponential on this path is of that kind: a covariance, the normal density.  The
 // algorithm and the coefficients are those of the device library's exp (range reduction by ln 2 in two parts, degree-11
-// polynomial, ldexp), the results identical to exp(x) bit for bit (scripts/exp_neg_probe.hip: 2^25 arguments and the special
+// polynomial, ldexp), the results identical to exp(x) bit for bit (tests/probes/exp_neg_probe.hip: 2^25 arguments and the special
 // values), but the polynomial's constants sit in scalar registers (fma_sc): 20 vector instructions fewer per value.
 __device__ __forceinline__ double exp_neg(double x) {
     constexpr double LOG2E = __builtin_bit_cast(double, 0x3ff71547652b82feULL);

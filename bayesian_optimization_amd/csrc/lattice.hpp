@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_lattice_rows(LatticeDesc L, const doubl
 // mode 0: the largest posterior mean after the update, which only the update itself can know -- but its location moves
 // rarely (195 of 200 iterations of the 64^4 loop keep it), so the new mean of the candidate that held the maximum so far
 // is formed here, bit for bit as the update will form it (an element of the fp64 MFMA product is the k-ordered chain of
-// fused multiply-adds from zero: scripts/mfma_chain_probe.hip), and used as the incumbent; the launch that ends the step
+// fused multiply-adds from zero: tests/probes/mfma_chain_probe.hip), and used as the incumbent; the launch that ends the step
 // compares it with the maximum the update found and, where they differ, the step falls back to the separate acquisition
 // pass.  mode 1: the largest observation (params[P_YMAX]).  mode 2: a given value.
 struct SpecArgs {

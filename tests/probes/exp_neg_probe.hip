@@ -1,13 +1,13 @@
 // exp_neg (csrc/kernels.hpp) against the device library's exp, bit for bit, over 2^25 arguments in [-1100, 0] (the range
 // the covariance functions and the normal density use), every exponent boundary region included, and the special values.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/exp_neg_probe scripts/exp_neg_probe.hip && scripts/exp_neg_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tests/probes/exp_neg_probe tests/probes/exp_neg_probe.hip && tests/probes/exp_neg_probe   (build() does the first half)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <random>
 #include <vector>
-#include "../bayesian_optimization_amd/csrc/kernels.hpp"
+#include "../../bayesian_optimization_amd/csrc/kernels.hpp"
 
 __global__ void k_both(const double* x, double* a, double* b, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

@@ -1,13 +1,13 @@
 // Is an element of the fp64 MFMA tile product the k-ordered chain of fused multiply-adds?  A 64 x 64 tile of A B (k = 16 ... 512)
 // on gemm_tile_64x64 against v = fma(A[i][k], B[k][j], v), k ascending from v = 0, bit for bit.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/mfma_chain_probe scripts/mfma_chain_probe.hip && scripts/mfma_chain_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tests/probes/mfma_chain_probe tests/probes/mfma_chain_probe.hip && tests/probes/mfma_chain_probe   (build() does the first half)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <random>
 #include <vector>
-#include "../bayesian_optimization_amd/csrc/kernels.hpp"
+#include "../../bayesian_optimization_amd/csrc/kernels.hpp"
 using namespace gpbo;
 
 __global__ __launch_bounds__(GEMM_THREADS) void k_tile(const double* A, long lda, const double* B, long ldb, int kpad, double* C) {
