@@ -355,7 +355,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void k_lattice_gemm_update_acq(con
 }
 
 // End of a step whose update launch carried the acquisition: the last stage of both reductions over the per-tile results, the
-// verdict on the incumbent (hit = the acquisition values are those of the separate pass), the end-of-step block (layout of
+// decision on the incumbent (hit = the acquisition values are those of the separate pass), the end-of-step block (layout of
 // k_step_end, plus res[12] = hit), the index of the largest mean for the next step's incumbent, and the incumbent slots.
 __global__ __launch_bounds__(1024) void k_spec_finish(TileBest in, long tiles, const double* __restrict__ params, const int* __restrict__ info,
                                                       double* __restrict__ spec, int need_match, int have, double* __restrict__ inc_out,
